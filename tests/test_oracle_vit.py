@@ -1,0 +1,147 @@
+"""Cross-checks of the oracle's ViT restatement (oracle/vit_ref.py): against the reference's
+vendored DINOv2 attention (dino_patch/attention.py, only where /root/reference is mounted)
+and against an independent implementation (HF transformers ViTModel / Dinov2Model built from
+local config objects — no download).  These do not pin the reference's third-party forward
+(parity unpinned, see oracle/vit_ref.py); they guard the restatement against slips."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import config, weights
+from oracle import ref_extract as rx
+from oracle import vit_ref
+
+
+def _tiny_cfg(layerscale: bool):
+    base = config.vit_config("dinov2_vits14" if layerscale else "dino_vits16", 56 if layerscale else 64)
+    return dataclasses.replace(base, dim=128, depth=3, heads=2, layer=2, native_grid=base.grid)
+
+
+def _frames(cfg, n=2, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(n, cfg.img_size, cfg.img_size, 3), dtype=np.uint8)
+
+
+def _oracle_tokens(cfg, sd, frames, return_all=False):
+    return vit_ref.block_tokens(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                mean=cfg.mean, std=cfg.std, return_all=return_all)
+
+
+@pytest.mark.skipif(not rx.available(), reason="reference tree not mounted")
+def test_attention_matches_vendored_dinov2_attention():
+    mod = rx.load_attention_module()
+    torch.manual_seed(0)
+    att = mod.Attention(128, num_heads=2, qkv_bias=True).eval()
+    x = torch.randn(2, 17, 128)
+    with torch.no_grad():
+        ref = att(x)
+        mine = vit_ref.attention(x, att.qkv.weight, att.qkv.bias, att.proj.weight, att.proj.bias, 2)
+    assert float((ref - mine).abs().max()) < 5e-6
+
+
+def test_forward_matches_hf_vit():
+    transformers = pytest.importorskip("transformers")
+    cfg = _tiny_cfg(False)
+    sd = weights.synthetic_state_dict(cfg, 1)
+    hf_cfg = transformers.ViTConfig(hidden_size=cfg.dim, num_hidden_layers=cfg.blocks_run,
+                                    num_attention_heads=cfg.heads, intermediate_size=cfg.hidden,
+                                    image_size=cfg.img_size, patch_size=cfg.patch, layer_norm_eps=cfg.ln_eps,
+                                    hidden_act="gelu", qkv_bias=True, hidden_dropout_prob=0.0,
+                                    attention_probs_dropout_prob=0.0)
+    model = transformers.ViTModel(hf_cfg, add_pooling_layer=False).eval()
+    m = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": sd["pos_embed"],
+         "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+         "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"]}
+    d = cfg.dim
+    for i in range(cfg.blocks_run):
+        s, t = f"blocks.{i}.", f"layers.{i}."
+        qw, qb = sd[s + "attn.qkv.weight"], sd[s + "attn.qkv.bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            m[t + f"attention.{nm}.weight"] = qw[j * d:(j + 1) * d]
+            m[t + f"attention.{nm}.bias"] = qb[j * d:(j + 1) * d]
+        m[t + "attention.o_proj.weight"] = sd[s + "attn.proj.weight"]
+        m[t + "attention.o_proj.bias"] = sd[s + "attn.proj.bias"]
+        m[t + "layernorm_before.weight"] = sd[s + "norm1.weight"]
+        m[t + "layernorm_before.bias"] = sd[s + "norm1.bias"]
+        m[t + "layernorm_after.weight"] = sd[s + "norm2.weight"]
+        m[t + "layernorm_after.bias"] = sd[s + "norm2.bias"]
+        m[t + "mlp.fc1.weight"] = sd[s + "mlp.fc1.weight"]
+        m[t + "mlp.fc1.bias"] = sd[s + "mlp.fc1.bias"]
+        m[t + "mlp.fc2.weight"] = sd[s + "mlp.fc2.weight"]
+        m[t + "mlp.fc2.bias"] = sd[s + "mlp.fc2.bias"]
+    missing, unexpected = model.load_state_dict(m, strict=False)
+    assert not [k for k in missing if not k.startswith("layernorm.")], missing
+    assert not unexpected
+    frames = _frames(cfg)
+    x = vit_ref.preprocess_u8(frames, cfg.mean, cfg.std)
+    with torch.no_grad():
+        hs = model(pixel_values=x, output_hidden_states=True).hidden_states
+    mine = _oracle_tokens(cfg, sd, frames, return_all=True)
+    assert len(hs) == len(mine)
+    for a, b in zip(hs, mine):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_forward_matches_hf_dinov2_layerscale():
+    transformers = pytest.importorskip("transformers")
+    cfg = _tiny_cfg(True)
+    sd = weights.synthetic_state_dict(cfg, 2)
+    hf_cfg = transformers.Dinov2Config(hidden_size=cfg.dim, num_hidden_layers=cfg.blocks_run,
+                                       num_attention_heads=cfg.heads, mlp_ratio=4, image_size=cfg.img_size,
+                                       patch_size=cfg.patch, layer_norm_eps=cfg.ln_eps, hidden_act="gelu",
+                                       qkv_bias=True, layerscale_value=1.0, use_swiglu_ffn=False,
+                                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                       drop_path_rate=0.0)
+    model = transformers.Dinov2Model(hf_cfg).eval()
+    own = model.state_dict()
+    m = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": sd["pos_embed"],
+         "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+         "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+         "embeddings.mask_token": own["embeddings.mask_token"]}
+    d = cfg.dim
+    for i in range(cfg.blocks_run):
+        s, t = f"blocks.{i}.", f"encoder.layer.{i}."
+        qw, qb = sd[s + "attn.qkv.weight"], sd[s + "attn.qkv.bias"]
+        for j, nm in enumerate(("query", "key", "value")):
+            m[t + f"attention.attention.{nm}.weight"] = qw[j * d:(j + 1) * d]
+            m[t + f"attention.attention.{nm}.bias"] = qb[j * d:(j + 1) * d]
+        m[t + "attention.output.dense.weight"] = sd[s + "attn.proj.weight"]
+        m[t + "attention.output.dense.bias"] = sd[s + "attn.proj.bias"]
+        m[t + "norm1.weight"] = sd[s + "norm1.weight"]
+        m[t + "norm1.bias"] = sd[s + "norm1.bias"]
+        m[t + "norm2.weight"] = sd[s + "norm2.weight"]
+        m[t + "norm2.bias"] = sd[s + "norm2.bias"]
+        m[t + "layer_scale1.lambda1"] = sd[s + "ls1.gamma"]
+        m[t + "layer_scale2.lambda1"] = sd[s + "ls2.gamma"]
+        m[t + "mlp.fc1.weight"] = sd[s + "mlp.fc1.weight"]
+        m[t + "mlp.fc1.bias"] = sd[s + "mlp.fc1.bias"]
+        m[t + "mlp.fc2.weight"] = sd[s + "mlp.fc2.weight"]
+        m[t + "mlp.fc2.bias"] = sd[s + "mlp.fc2.bias"]
+    missing, unexpected = model.load_state_dict(m, strict=False)
+    assert not [k for k in missing if not k.startswith("layernorm.")], missing
+    assert not unexpected
+    frames = _frames(cfg)
+    x = vit_ref.preprocess_u8(frames, cfg.mean, cfg.std)
+    with torch.no_grad():
+        hs = model(pixel_values=x, output_hidden_states=True).hidden_states
+    mine = _oracle_tokens(cfg, sd, frames, return_all=True)
+    for a, b in zip(hs, mine):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_descriptor_drops_cls_and_bins():
+    cfg = _tiny_cfg(False)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    frames = _frames(cfg, 1)
+    toks = _oracle_tokens(cfg, sd, frames)
+    kw = dict(patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+    d = vit_ref.extract_descriptors(sd, frames, **kw)
+    assert d.shape == (1, 1, cfg.tokens, cfg.dim)
+    assert torch.equal(d[0, 0], toks[0, 1:])
+    b = vit_ref.extract_descriptors(sd, frames, bin=True, **kw)
+    assert b.shape == (1, 1, cfg.tokens, 9 * cfg.dim)
+    centre = b[0, 0, :, 4 * cfg.dim:5 * cfg.dim]
+    assert torch.equal(centre, toks[0, 1:])
