@@ -1,0 +1,154 @@
+/*
+ * vitvs.h — C ABI of the MI355X-native ViT-VS hot path (libvitvs_hip.so).
+ *
+ * The reference (begbaj/ViT-VS) has no FFI: the hot path sits behind Python bound methods.
+ * Each entry point below names the reference interface it replaces (paths under
+ * /root/reference/catkin_ws/ibvs/src unless noted).  The Python binding a maintainer adds is
+ * shown in INTEGRATION.md (ctypes), and vit-vs_amd/_lib.py is exactly that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures (streams travel as void*).
+ *   - every function returns a status: 0 ok, > 0 a servo status (enum below), < 0 an error;
+ *     vitvs_last_error() gives the message.  Nothing throws across the boundary.
+ *   - "_dev" functions take DEVICE pointers and enqueue work on the given hipStream_t (void*,
+ *     NULL = the null stream) without synchronising; outputs are valid once the stream has reached
+ *     the end of the call's work.  The un-suffixed forms take HOST pointers, copy, run and wait.
+ *   - inputs are borrowed for the duration of the call; outputs go to caller-allocated buffers;
+ *     the handle owns the device weights and workspaces.  One in-flight call per handle; a handle
+ *     is bound to the HIP device that was current when it was created.
+ *   - images are RGB uint8, HWC, already resized to img_size x img_size (reference:
+ *     vitvs_v2.py:474-475 PIL resize happens before the path; dinov2_extractor.py:177-191).
+ *   - depth is the sensor's uint16 millimetre image, 0 = invalid (reference:
+ *     realsense_gazebo_plugin/src/RealSensePlugin.cpp:250-262, consumed at vitvs_v2.py:566-586).
+ */
+#ifndef VITVS_H
+#define VITVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITVS_ABI_VERSION 1
+#define VITVS_API __attribute__((visibility("default")))
+
+typedef struct vitvs_handle vitvs_handle;
+
+enum vitvs_precision { VITVS_F32 = 0, VITVS_BF16 = 1 };
+
+/* Servo status (reference error convention):
+ *   NO_CORRESPONDENCE  find_correspondences_batch returned (None, None, None)   vitvs_v2.py:155, 500-505
+ *   TOO_FEW            < 4 matches: calculate_uv returns all-zero features       vitvs_v2.py:539-541
+ *   NO_DEPTH           no depth image: ibvs() returns early                      vitvs_v2.py:616-619 */
+enum vitvs_status { VITVS_OK = 0, VITVS_NO_CORRESPONDENCE = 1, VITVS_TOO_FEW = 2, VITVS_NO_DEPTH = 3 };
+
+/* How the servo features are drawn from the mutual-nearest-neighbour candidates
+ * (reference: torch.randperm subset, vitvs_v2.py:134-141; see DESIGN.md "Selection"). */
+enum vitvs_select {
+    VITVS_SELECT_EXPLICIT = 0, /* caller passes the chosen token ids of the desired frame            */
+    VITVS_SELECT_ORDER = 1,    /* caller passes a visiting order (permutation of 0..T-1); the first  */
+                               /* num_pairs candidates met in that order are used                    */
+    VITVS_SELECT_DENSE = 2     /* every candidate, ascending token id (no zero padding)              */
+};
+
+typedef struct vitvs_config {
+    int32_t abi_version;  /* VITVS_ABI_VERSION */
+    /* extractor geometry (reference: ViTExtractor.__init__, dinov2_extractor.py:25-55) */
+    int32_t img_size;     /* S */
+    int32_t patch;        /* p */
+    int32_t stride;       /* patch-embed stride (== patch unless the stride hack is used, :122-144) */
+    int32_t dim;          /* D, multiple of 128 */
+    int32_t heads;        /* H, D / H must be 64 */
+    int32_t blocks;       /* blocks to run = layer + 1 (descriptor = output of blocks[layer], :226-229) */
+    int32_t layerscale;   /* 1: DINOv2 layout with ls1/ls2 gammas (dino_patch/block.py:73,85) */
+    float mean[3];        /* Normalize constants (dinov2_extractor.py:49-50) */
+    float std[3];
+    float ln_eps;         /* 1e-6 */
+    int32_t precision;    /* vitvs_precision of the ViT GEMMs/attention; the correspondence and the law are fp32/fp64 */
+    int32_t binned;       /* 1: 3x3 log-bin descriptors (use_feature_binning, dinov2_extractor.py:265-311) */
+    /* control law (reference: config.yaml:1-17; vitvs_v2.py:278-295) */
+    int32_t num_pairs;
+    int32_t u_max, v_max; /* camera resolution; also the depth image size */
+    double lambda;
+    /* capacity */
+    int32_t max_pairs;    /* frame pairs per call (B) */
+    int32_t max_rows;     /* feature pairs per frame pair the law may use (>= num_pairs; >= T enables DENSE) */
+} vitvs_config;
+
+/* --- lifetime --------------------------------------------------------------------------------
+ * Replaces ViTExtractor(model_type, stride, model=...) + model.to(device) (dinov2_extractor.py:25-55). */
+VITVS_API int vitvs_create(const vitvs_config* cfg, vitvs_handle** out);
+VITVS_API void vitvs_destroy(vitvs_handle* h);
+VITVS_API const char* vitvs_last_error(const vitvs_handle* h); /* h may be NULL: last creation error */
+VITVS_API int vitvs_abi_version(void);
+
+/* --- weights ---------------------------------------------------------------------------------
+ * Replaces model.load_state_dict (dinov2_extractor.py:79-82).  `name` is the DINO/timm/DINOv2
+ * state-dict key (patch_embed.proj.weight, cls_token, pos_embed — already resampled to the token
+ * grid, shape [1+T][D] —, blocks.{i}.norm1.weight, ... , blocks.{i}.ls2.gamma); `data` is fp32 on
+ * the host.  vitvs_weights_ready returns 0 when every tensor the forward reads has been set. */
+VITVS_API int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64_t numel);
+VITVS_API int vitvs_weights_ready(const vitvs_handle* h);
+
+/* --- the hot path ----------------------------------------------------------------------------
+ * compute_velocity(I_cur, I_des, Z, K) -> v_c : Controller.detect_features() + Controller.ibvs()
+ * up to the raw (pre-EMA) twist (vitvs_v2.py:464-523, 588-622).
+ *   n_pairs          frame pairs in this call (<= max_pairs)
+ *   I_cur, I_des     uint8 [n_pairs][S][S][3]; if des_shared != 0, I_des is ONE image used for all
+ *                    pairs (rotation compensation, vitvs_v2.py:1151-1189)
+ *   Z_mm             uint16 [n_pairs][v_max][u_max], or NULL -> status NO_DEPTH
+ *   K                double [n_pairs][4] = fx, fy, cx, cy
+ *   select_mode      vitvs_select; `selection` int32: EXPLICIT [n_pairs][num_pairs] token ids with
+ *                    n_selected[n_pairs] counts; ORDER [n_pairs][T]; DENSE ignored (NULL)
+ *   v_c              double [n_pairs][6] = vx, vy, vz, wx, wy, wz (camera optical frame)
+ *   status           int32 [n_pairs] vitvs_status
+ * The return value is < 0 on error, else 0 (per-pair statuses are in `status`). */
+VITVS_API int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
+                               int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
+                               const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
+                               void* stream);
+VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
+                           int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
+                           const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status);
+
+/* --- the seams inside it (same split as the reference's callables) ------------------------------
+ * ViTExtractor.extract_descriptors(batch, layer, 'token', bin) (dinov2_extractor.py:313-337):
+ * frames uint8 [n][S][S][3] -> desc fp32 [n][T][D'] (D' = D, or 9D when cfg.binned); raw, un-normalised. */
+VITVS_API int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* desc,
+                                  void* stream);
+/* Residual stream after block `cfg.blocks - 1`, fp32 [n][1+T][D] (what the forward hook captures,
+ * dinov2_extractor.py:198-199), for parity tests. */
+VITVS_API int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream);
+
+/* find_correspondences_batch's similarity + argmax stage (vitvs_v2.py:78-81) on caller descriptors:
+ * desc1 (desired), desc2 (current) fp32 [T][Dp], Dp a multiple of 32 -> nn_1, nn_2 int32 [T], sim_1 fp32 [T].
+ * Optional S_out fp32 [T][T] receives the full similarity matrix (NULL to skip). */
+VITVS_API int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* desc1, const float* desc2,
+                         int32_t* nn_1, int32_t* nn_2, float* sim_1, float* S_out, void* stream);
+
+/* The control law on given nearest-neighbour tables (vitvs_v2.py:105-155 filter/selection, :511-553,
+ * :566-586, :613-659): nn_1, nn_2 int32 [T], sim_1 fp32 [T] for ONE pair. */
+VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, const int32_t* nn_2, const float* sim_1,
+                            const uint16_t* Z_mm, const double* K, int32_t select_mode, const int32_t* selection,
+                            int32_t n_selected, double* v_c, int32_t* status, void* stream);
+
+/* --- introspection of the last compute_velocity / servo call (device -> host copies, synchronising).
+ * What detect_features() returns besides v_c (vitvs_v2.py:523) and what the parity tests check.
+ *   nn_1, nn_2 int32 [n_pairs][T]; sim_1 fp32 [n_pairs][T]
+ *   info int32 [n_pairs][8]: n_mutual, n_feature_rows, same_image, n_matched, svd_sweeps, L_rows, 0, 0
+ *   selected int32 [n_pairs][max_rows] token ids of the desired frame (-1 = zero-padded row)
+ *   s_uv int32 [n_pairs][max_rows][4] = u*, v*, u, v ; feat double [n_pairs][max_rows][4] = Z, x, y, sim
+ *   L double [n_pairs][7][2*max_rows] column-major: 6 columns of L_e then e.
+ * Any pointer may be NULL. */
+VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,
+                       int32_t* selected, int32_t* s_uv, double* feat, double* L);
+
+/* Token count T and descriptor width D' for this handle. */
+VITVS_API int vitvs_tokens(const vitvs_handle* h);
+VITVS_API int vitvs_desc_dim(const vitvs_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITVS_H */

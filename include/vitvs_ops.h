@@ -1,0 +1,36 @@
+/*
+ * vitvs_ops.h — single-operator entry points of libvitvs_hip.so, exported so that the
+ * kernel-level parity tests (tests/test_gpu_ops.py) can drive each HIP kernel through the C ABI.
+ * Not part of the drop-in surface; the reference issues these as stock PyTorch ops:
+ *   linear / linear_residual   nn.Linear (+ GELU, + LayerScale and residual add)  dino_patch/attention.py:72,79; block.py:78-96
+ *   layernorm                  nn.LayerNorm(eps=1e-6)                              dino_patch/block.py:57,75
+ *   attention                  scaled_dot_product_attention over [B,H,N,64]        dino_patch/attention.py:73-78
+ * All pointers are device pointers; `precision` is enum vitvs_precision; `stream` a hipStream_t.
+ */
+#ifndef VITVS_OPS_H
+#define VITVS_OPS_H
+#include <stdint.h>
+#ifndef VITVS_API
+#define VITVS_API __attribute__((visibility("default")))
+#endif
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[M][N] = act(A[M][K] . W[N][K]^T + bias[N]); A, W, out in `precision`; K % 64 == 0, N % 64 == 0 */
+VITVS_API int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float* bias, void* out, int32_t M,
+                    int32_t N, int32_t K, int32_t gelu, void* stream);
+/* x[M][N] (fp32) += ls[N] * (A . W^T + bias); ls may be NULL */
+VITVS_API int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
+                             float* x, int32_t M, int32_t N, int32_t K, void* stream);
+/* out[M][D] = LayerNorm(x[M][D]) * gamma + beta; x fp32, out in `precision`; D in {128,256,384,768,1024} */
+VITVS_API int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
+                       int32_t D, float eps, void* stream);
+/* out[n_img*N][H*64] = softmax(q k^T / 8) v per (image, head); qkv [n_img*N][3*H*64] */
+VITVS_API int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: libvitvs_hip.so builds (hipcc cross-compiles gfx950
+without a GPU), loads, and exports every symbol include/*.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def _declared(header):
+    with open(os.path.join(ROOT, "include", header)) as fh:
+        text = fh.read()
+    return set(re.findall(r"VITVS_API\s+[\w\s\*]+?\b(vitvs_\w+)\s*\(", text))
+
+
+def test_headers_and_binding_agree(lib):
+    declared = _declared("vitvs.h") | _declared("vitvs_ops.h")
+    assert declared, "no prototypes found in include/"
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared("vitvs.h") | _declared("vitvs_ops.h"):
+        assert hasattr(raw, name), f"{name} not exported"
+
+
+def test_abi_version_and_config_layout(lib):
+    assert lib.vitvs_abi_version() == _lib.ABI_VERSION
+    # struct vitvs_config: 8 int32, 7 float, 5 int32, double, 2 int32 -> 96 bytes (static_assert'ed in api.hip)
+    assert ctypes.sizeof(_lib.VitvsConfig) == 96
+    assert _lib.VitvsConfig.lambda_.offset == 80
+
+
+def test_create_rejects_bad_config_without_touching_a_gpu(lib):
+    cfg = _lib.VitvsConfig()
+    cfg.abi_version = 999
+    h = ctypes.c_void_p()
+    assert lib.vitvs_create(ctypes.byref(cfg), ctypes.byref(h)) < 0
+    assert b"abi_version" in lib.vitvs_last_error(None)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from vitvs_amd import config
+    from vitvs_amd.engine import Engine, VitvsError
+    with pytest.raises(VitvsError):
+        Engine(config.baseline_config("vits16_224"))

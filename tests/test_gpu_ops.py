@@ -1,0 +1,146 @@
+"""Kernel-level parity (GPU): every HIP operator of the forward, driven through the C ABI
+(include/vitvs_ops.h), against a plain PyTorch fp32/fp64 statement of the same op.
+
+Tolerances: fp32 kernels run exact-fp32 MFMA chains, so they must agree with an fp64 reference
+to fp32 rounding (<= 2e-5 relative to the output scale); bf16 kernels are compared with an fp64
+reference evaluated on the SAME bf16-rounded inputs (<= 1.5e-2, the output rounding)."""
+import ctypes as C
+
+import pytest
+import torch
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 1.5e-2
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _mk(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).float()
+
+
+PRECS = [("fp32", _lib.F32, torch.float32, F32_TOL), ("bf16", _lib.BF16, torch.bfloat16, BF16_TOL)]
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,N,K,gelu", [(394, 384, 128, 0), (394, 2304, 768, 0), (77, 512, 192, 1), (1200, 3072, 768, 1),
+                                        (64, 64, 64, 0), (5, 128, 640, 1)])
+def test_linear(lib, name, prec, dtype, tol, M, N, K, gelu):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((N, K), g, K ** -0.5).to(dtype)
+    bias = _mk((N,), g, 0.1)
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    rc = lib.vitvs_op_linear(prec, _p(Ad), _p(Wd), _p(bd), _p(out), M, N, K, gelu, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert _rel(out.cpu(), ref) <= tol
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,N,K,use_ls", [(394, 768, 768, False), (394, 768, 3072, True), (130, 384, 1536, True)])
+def test_linear_residual(lib, name, prec, dtype, tol, M, N, K, use_ls):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((N, K), g, K ** -0.5).to(dtype)
+    bias = _mk((N,), g, 0.1)
+    ls = (1.0 + 0.3 * _mk((N,), g)) if use_ls else None
+    x0 = _mk((M, N), g)
+    upd = A.double() @ W.double().t() + bias.double()
+    if use_ls:
+        upd = upd * ls.double()
+    ref = x0.double() + upd
+    x = x0.clone().cuda()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    lsd = ls.cuda() if use_ls else None
+    rc = lib.vitvs_op_linear_residual(prec, _p(Ad), _p(Wd), _p(bd), _p(lsd), _p(x), M, N, K, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert _rel(x.cpu(), ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)  # bf16: fp32 accumulate, fp32 output
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,D", [(394, 768), (394, 384), (7, 1024), (1, 128), (2740, 1024)])
+def test_layernorm(lib, name, prec, dtype, tol, M, D):
+    g = torch.Generator().manual_seed(D + M)
+    x = _mk((M, D), g, 3.0) + 0.7
+    gamma = 1.0 + 0.1 * _mk((D,), g)
+    beta = 0.1 * _mk((D,), g)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6)
+    out = torch.empty((M, D), dtype=dtype, device="cuda")
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
+    rc = lib.vitvs_op_layernorm(prec, _p(xd), _p(gd), _p(bd), _p(out), M, D, 1e-6, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) <= (5e-6 if prec == _lib.F32 else 8e-3)
+
+
+def _attention_ref(qkv, n_img, N, H):
+    D = H * 64
+    q, k, v = qkv.double().reshape(n_img, N, 3, H, 64).unbind(2)
+    q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+    att = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    return (att @ v).transpose(1, 2).reshape(n_img * N, D)
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("n_img,N,H,scale", [(2, 197, 6, 1.0), (1, 64, 2, 1.0), (1, 70, 1, 3.0), (2, 257, 2, 2.0),
+                                             (1, 1370, 2, 1.0), (3, 5, 1, 1.0)])
+def test_attention(lib, name, prec, dtype, tol, n_img, N, H, scale):
+    g = torch.Generator().manual_seed(N * 3 + H)
+    D = H * 64
+    qkv = _mk((n_img * N, 3 * D), g, scale).to(dtype)
+    ref = _attention_ref(qkv, n_img, N, H)
+    out = torch.full((n_img * N, D), float("nan"), dtype=dtype, device="cuda")
+    qd = qkv.cuda()
+    rc = lib.vitvs_op_attention(prec, _p(qd), _p(out), n_img, N, H, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert _rel(out.cpu(), ref) <= (1e-5 if prec == _lib.F32 else 2e-2)
+
+
+def test_attention_asymmetric_values_catch_transposed_operands(lib):
+    """V with a per-dimension ramp and one-hot attention: any key/dim permutation slip in the PV
+    product (transposed LDS reads, permuted MFMA k-slots) shows up as an O(1) error."""
+    N, H = 130, 1
+    qkv = torch.zeros((N, 192), dtype=torch.float32)
+    keys = torch.arange(N, dtype=torch.float32)
+    qkv[:, 0] = 40.0  # q . k = 40 * k[0]
+    qkv[:, 64] = torch.where(keys == 77, 40.0, -40.0)  # softmax collapses onto key 77
+    qkv[:, 128:192] = keys[:, None] * 0.5 + torch.arange(64, dtype=torch.float32)[None, :] * 0.01
+    ref = _attention_ref(qkv, 1, N, H)
+    for prec, dtype, tol in ((_lib.F32, torch.float32, 1e-5), (_lib.BF16, torch.bfloat16, 1e-2)):
+        q = qkv.to(dtype)
+        out = torch.empty((N, 64), dtype=dtype, device="cuda")
+        qd = q.cuda()
+        assert lib.vitvs_op_attention(prec, _p(qd), _p(out), 1, N, H, _stream()) == 0
+        torch.cuda.synchronize()
+        assert _rel(out.cpu(), _attention_ref(q, 1, N, H)) <= tol
+    assert float(ref[0, 0]) == pytest.approx(38.5, abs=1e-6)

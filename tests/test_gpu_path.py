@@ -1,0 +1,343 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures.  Bars (BASELINE.json north_star):
+  * token-index argmax correspondences nn_1 / nn_2: bit-exact (fp32 mode, fixtures that meet the
+    margin acceptance rule); tie-tolerant on the many-token fixtures whose margins are ~1e-6;
+  * integer pixel features s_uv, s_uv*: bit-exact; Z exact; L_e to 1e-14; v_c <= 1e-4 relative L2
+    (asserted at 1e-9: the law runs in fp64 on both sides).
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import _lib, config, synth, weights
+from oracle import servo_ref as sr
+from oracle import vit_ref
+from conftest import golden_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+VC_TOL = 1e-4  # north_star: relative L2 on v_c
+
+
+def _engine(cfg, **kw):
+    from vitvs_amd.engine import Engine
+    return Engine(cfg, **kw)
+
+
+def _tiny_cfg(layerscale=False, img=64):
+    base = config.vit_config("dinov2_vits14" if layerscale else "dino_vits16", 56 if layerscale else img)
+    return dataclasses.replace(base, dim=128, depth=2, heads=2, layer=1, native_grid=base.grid)
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _oracle_tokens(cfg, sd, frames):
+    return vit_ref.block_tokens(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                mean=cfg.mean, std=cfg.std)
+
+
+# ----------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("layerscale", [False, True])
+def test_forward_tokens_tiny_fp32(layerscale):
+    cfg = _tiny_cfg(layerscale)
+    sd = weights.synthetic_state_dict(cfg, 11)
+    frames = np.random.default_rng(0).integers(0, 256, size=(3, cfg.img_size, cfg.img_size, 3), dtype=np.uint8)
+    eng = _engine(cfg, precision="fp32", max_pairs=2).load_state_dict(sd)
+    got = eng.forward_tokens(frames).cpu()
+    ref = _oracle_tokens(cfg, sd, frames)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_forward_tokens_resampled_pos_embed_and_stride():
+    """Strided (overlapping) patch embedding + bicubic pos-embed resampling (dinov2_extractor.py:85-144)."""
+    base = config.vit_config("dino_vits16", 64, stride=8)
+    cfg = dataclasses.replace(base, dim=128, depth=1, heads=2, layer=0, native_grid=4)
+    sd = weights.synthetic_state_dict(cfg, 5)
+    frames = np.random.default_rng(1).integers(0, 256, size=(2, 64, 64, 3), dtype=np.uint8)
+    eng = _engine(cfg, precision="fp32", max_pairs=1).load_state_dict(sd)
+    got = eng.forward_tokens(frames).cpu()
+    ref = _oracle_tokens(cfg, sd, frames)
+    assert got.shape == (2, 1 + 49, 128)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("key", ["vits16_224", "vitb16_224", "vits14_308"])
+def test_forward_tokens_fp32_full_size(key):
+    blob = load_golden(f"e2e_{key}.npz")
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    eng = _engine(cfg, precision="fp32", max_pairs=1).load_state_dict(sd)
+    got = eng.forward_tokens(np.stack([des, cur])).cpu()
+    np.testing.assert_allclose(got[:, ::37, ::97].numpy(), blob["token_probe"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got.norm(dim=-1).numpy(), blob["token_norms"], rtol=1e-5)
+
+
+def test_descriptors_plain_and_binned():
+    cfg = _tiny_cfg(False, img=96)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    frames = np.random.default_rng(2).integers(0, 256, size=(2, 96, 96, 3), dtype=np.uint8)
+    ref = _oracle_tokens(cfg, sd, frames)[:, 1:]
+    for binned in (False, True):
+        eng = _engine(cfg, precision="fp32", max_pairs=1, binned=binned).load_state_dict(sd)
+        d = eng.extract_descriptors(frames).cpu()
+        want = vit_ref.log_bin(ref, cfg.grid) if binned else ref
+        assert d.shape == (2, 1, cfg.tokens, cfg.dim * (9 if binned else 1))
+        assert float((d[:, 0] - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        if binned:  # binning is a pure copy of the engine's own tokens
+            toks = eng.forward_tokens(frames)[:, 1:].cpu()
+            assert torch.equal(d[:, 0], vit_ref.log_bin(toks, cfg.grid))
+
+
+# ----------------------------------------------------------------------------- correspondence
+CORR_CASES = ["partial", "short", "tiny", "all_mutual", "grid14", "same_image"]
+
+
+@pytest.fixture(scope="module")
+def small_engine():
+    cfg = _tiny_cfg(False, img=224)  # T = 196 capacity, img_size 224 as in the fixtures
+    return _engine(cfg, precision="fp32", max_pairs=1, max_rows=196)
+
+
+@pytest.mark.parametrize("name", CORR_CASES)
+def test_correspond_matches_reference_argmax(small_engine, name):
+    case = golden_case(load_golden("corr_cases.npz"), name)
+    d1, d2 = torch.from_numpy(case["desc1"]), torch.from_numpy(case["desc2"])
+    nn1, nn2, sim1, smat = small_engine.correspond(d1, d2, want_matrix=True)
+    assert np.array_equal(nn1.cpu().numpy(), case["nn_1"])       # bit-exact token indices
+    assert np.array_equal(nn2.cpu().numpy(), case["nn_2"])
+    np.testing.assert_allclose(sim1.cpu().numpy(), case["sim_1"], rtol=0, atol=3e-7)
+    ref = sr.cosine_matrix(d1, d2)
+    assert float((smat.cpu() - ref).abs().max()) <= 5e-7
+    assert torch.equal(smat.max(dim=1).indices.cpu().int(), nn1.cpu())  # fused argmax == argmax of the dense matrix
+    assert torch.equal(smat.max(dim=0).indices.cpu().int(), nn2.cpu())
+
+
+def test_correspond_first_index_on_exact_ties(small_engine):
+    """Duplicate descriptors create exactly equal similarities; torch.max keeps the first index."""
+    g = torch.Generator().manual_seed(9)
+    d1 = torch.randn(64, 32, generator=g)
+    d2 = d1.clone()
+    d2[40] = d2[3]
+    d2[41] = d2[3]
+    d1[10] = d1[50]
+    nn1, nn2, _ = small_engine.correspond(d1, d2)
+    s = sr.cosine_matrix(d1, d2)
+    _, r1, _, r2 = sr.nearest_neighbours(s)
+    assert np.array_equal(nn1.cpu().numpy(), r1.numpy()) and np.array_equal(nn2.cpu().numpy(), r2.numpy())
+    assert int(nn1[3]) == 3 and int(nn2[40]) == 3
+
+
+# ----------------------------------------------------------------------------- control law
+def _ids(points_rc, grid):
+    return (points_rc[:, 0] * grid + points_rc[:, 1]).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", CORR_CASES)
+def test_servo_law_matches_reference_given_selection(name):
+    case = golden_case(load_golden("corr_cases.npz"), name)
+    t = case["nn_1"].shape[0]
+    grid = int(np.sqrt(t))
+    k = int(case["num_pairs"])
+    cfg = _tiny_cfg(False, img=224)
+    params = config.ServoParams(num_pairs=k, dino_input_size=224)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=max(k, 196))
+    status_ref = int(case["status"])
+    sel = _ids(case["points1"], grid) if status_ref != 1 else np.zeros(0, np.int32)
+    v, st = eng.servo_from_nn(case["nn_1"], case["nn_2"], case["sim_1"], synth.depth_pattern(),
+                              params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+    det = eng.last_details(1)
+    assert int(st) == status_ref
+    mutual = int((case["nn_2"][case["nn_1"]] == np.arange(t)).sum())
+    assert int(det["info"][0, 0]) == mutual
+    if status_ref == 1:
+        return
+    suv = det["s_uv"][0, :k]
+    assert np.array_equal(suv[:, 0:2], case["s_uv_star"]) and np.array_equal(suv[:, 2:4], case["s_uv"])
+    assert np.array_equal(det["feat"][0, :k, 0:1], case["Z"])
+    L = det["L"][0, :6, :2 * k].T
+    np.testing.assert_allclose(L, case["L"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(det["L"][0, 6, :2 * k], case["e"][:, 0], rtol=0, atol=1e-15)
+    if status_ref == 0:
+        assert _rel_l2(v.cpu().numpy(), case["v_c"]) <= 1e-9 <= VC_TOL
+    else:
+        assert np.all(v.cpu().numpy() == 0.0)
+
+
+def test_servo_order_and_dense_selection_match_oracle():
+    case = golden_case(load_golden("corr_cases.npz"), "grid14")
+    t, grid, k = 196, 14, 24
+    params = config.ServoParams(num_pairs=k, dino_input_size=224)
+    eng = _engine(_tiny_cfg(False, img=224), params, precision="fp32", max_pairs=1, max_rows=196)
+    depth = synth.depth_pattern()
+    nn1, nn2 = case["nn_1"].astype(np.int64), case["nn_2"].astype(np.int64)
+    mutual = np.nonzero(nn2[nn1] == np.arange(t))[0]
+    order = np.random.default_rng(4).permutation(t).astype(np.int32)
+    want = [i for i in order if i in set(mutual.tolist())][:k]
+
+    def oracle(ids, rows):
+        p1 = torch.from_numpy(np.stack([np.asarray(ids) // grid, np.asarray(ids) % grid], 1))
+        p2 = torch.from_numpy(np.stack([nn1[ids] // grid, nn1[ids] % grid], 1))
+        s_star, s = sr.calculate_uv(sr.patch_centres(p1, 224, grid), sr.patch_centres(p2, 224, grid), rows,
+                                    params.u_max, params.v_max, 224)
+        return sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+
+    v, st = eng.servo_from_nn(nn1, nn2, case["sim_1"], depth, params.intrinsics(), mode=_lib.SELECT_ORDER,
+                              selection=order)
+    det = eng.last_details(1)
+    assert int(st) == 0 and det["selected"][0, :k].tolist() == [int(x) for x in want]
+    assert _rel_l2(v.cpu().numpy(), oracle(np.array(want), k)["v_c"]) <= 1e-9
+    v, st = eng.servo_from_nn(nn1, nn2, case["sim_1"], depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    det = eng.last_details(1)
+    assert int(st) == 0 and det["selected"][0, :len(mutual)].tolist() == mutual.tolist()
+    assert int(det["info"][0, 1]) == len(mutual)
+    assert _rel_l2(v.cpu().numpy(), oracle(mutual, len(mutual))["v_c"]) <= 1e-9
+
+
+def test_servo_no_depth_status():
+    case = golden_case(load_golden("corr_cases.npz"), "partial")
+    params = config.ServoParams(num_pairs=24, dino_input_size=224)
+    eng = _engine(_tiny_cfg(False, img=224), params, precision="fp32", max_pairs=1, max_rows=196)
+    v, st = eng.servo_from_nn(case["nn_1"], case["nn_2"], case["sim_1"], None, params.intrinsics(),
+                              mode=_lib.SELECT_DENSE)
+    assert int(st) == _lib.STATUS_NO_DEPTH and np.all(v.cpu().numpy() == 0)
+
+
+def test_pinv_rank_deficient_matches_numpy():
+    """All selected features identical -> rank-2 L_e; the SVD cut-off (rcond 1e-15) must agree with numpy."""
+    t, grid, k = 64, 8, 8
+    nn1 = np.arange(t, dtype=np.int32)
+    nn2 = np.arange(t, dtype=np.int32)
+    nn1[5], nn1[6] = 6, 5   # two non-mutual tokens so that the filter does not return None
+    params = config.ServoParams(num_pairs=k, dino_input_size=224)
+    eng = _engine(_tiny_cfg(False, img=224), params, precision="fp32", max_pairs=1, max_rows=196)
+    sel = np.full(k, 9, np.int32)
+    nn1[9] = 27             # a displaced match so that e != 0
+    nn2[27] = 9
+    nn2[9] = 63
+    depth = synth.depth_pattern()
+    v, st = eng.servo_from_nn(nn1, nn2, np.full(t, 0.5, np.float32), depth, params.intrinsics(),
+                              mode=_lib.SELECT_EXPLICIT, selection=[sel])
+    p1 = torch.tensor([[9 // grid, 9 % grid]] * k)
+    p2 = torch.tensor([[27 // grid, 27 % grid]] * k)
+    s_star, s = sr.calculate_uv(sr.patch_centres(p1, 224, grid), sr.patch_centres(p2, 224, grid), k, params.u_max,
+                                params.v_max, 224)
+    ref = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+    assert np.linalg.matrix_rank(ref["L"]) == 2
+    assert _rel_l2(v.cpu().numpy(), ref["v_c"]) <= 1e-9
+
+
+# ----------------------------------------------------------------------------- end to end
+def _e2e(key, tag, precision):
+    blob = load_golden(f"e2e_{key}.npz")
+    case = golden_case(blob, tag)
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=(tag == "binned"))
+    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    sel = _ids(case["points1"], cfg.grid)
+    v, st = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_EXPLICIT,
+                                 selection=[sel])
+    return case, eng.last_details(1), v.cpu().numpy()[0], int(st[0])
+
+
+@pytest.mark.parametrize("key,tag", [("vits16_224", "plain"), ("vits16_224", "binned"), ("vitb16_224", "plain"),
+                                     ("vitb16_224", "binned"), ("vits14_308", "binned")])
+def test_compute_velocity_fp32_matches_reference(key, tag):
+    case, det, v, st = _e2e(key, tag, "fp32")
+    assert bool(case["strict"])
+    assert st == 0
+    assert np.array_equal(det["nn_1"][0], case["nn_1"])   # bit-exact argmax correspondences
+    assert np.array_equal(det["nn_2"][0], case["nn_2"])
+    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-5)
+    k = case["s_uv"].shape[0]
+    assert np.array_equal(det["s_uv"][0, :k, 2:4], case["s_uv"]) and np.array_equal(det["s_uv"][0, :k, 0:2], case["s_uv_star"])
+    assert _rel_l2(v, case["v_c"]) <= 1e-9 <= VC_TOL
+
+
+def _tie_tolerant_agreement(got, ref_idx, sim_ref_rows, tol):
+    """Every disagreement must be a numerical tie in the oracle's similarities."""
+    bad = np.nonzero(got != ref_idx)[0]
+    for i in bad:
+        assert sim_ref_rows[i, ref_idx[i]] - sim_ref_rows[i, got[i]] <= tol, (i, got[i], ref_idx[i])
+    return 1.0 - len(bad) / len(ref_idx)
+
+
+@pytest.mark.parametrize("key", ["vitl14_518", "vitb8_448"])
+def test_compute_velocity_fp32_many_tokens(key):
+    """BASELINE configs #3/#5: thousands of tokens, top-1/top-2 margins ~1e-6, so index parity is
+    judged tie-tolerantly against the oracle's similarity matrix; v_c given the reference selection."""
+    case, det, v, st = _e2e(key, "plain", "fp32")
+    cfg = config.baseline_config(key)
+    blob = load_golden(f"e2e_{key}.npz")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+    S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
+    a1 = _tie_tolerant_agreement(det["nn_1"][0], case["nn_1"], S, 2e-5)
+    a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, 2e-5)
+    assert a1 >= 0.99 and a2 >= 0.99
+    assert st == 0
+    # v_c depends on nn_1 at the selected tokens only; require those to agree, then the law must match
+    sel = _ids(case["points1"], cfg.grid)
+    if np.array_equal(det["nn_1"][0][sel], case["nn_1"][sel]):
+        assert _rel_l2(v, case["v_c"]) <= 1e-9
+
+
+def test_compute_velocity_bf16_reports_agreement():
+    """bf16 throughput mode: not bit-exact by construction; it must stay close to the fp32 oracle."""
+    case, det, v, st = _e2e("vitb16_224", "plain", "bf16")
+    agree1 = float((det["nn_1"][0] == case["nn_1"]).mean())
+    agree2 = float((det["nn_2"][0] == case["nn_2"]).mean())
+    print(f"bf16 argmax agreement nn_1={agree1:.3f} nn_2={agree2:.3f} v_c rel err={_rel_l2(v, case['v_c']):.3e}")
+    assert st == 0 and np.all(np.isfinite(v))
+    assert agree1 >= 0.85 and agree2 >= 0.85
+    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-2)
+
+
+def test_batched_pairs_and_shared_goal():
+    """B pairs in one call == B single calls (bit-identical), and des_shared == repeated I_des."""
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
+    pairs = [synth.frame_pair(224, 20250705 + i) for i in range(3)]
+    des = np.stack([p[0] for p in pairs])
+    cur = np.stack([p[1] for p in pairs])
+    depth = np.stack([synth.depth_pattern()] * 3)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=3, max_rows=196).load_state_dict(sd)
+    vb, sb = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    detb = eng.last_details(3)
+    for i in range(3):
+        v1, s1 = eng.compute_velocity(cur[i], des[i], depth[i], params.intrinsics(), mode=_lib.SELECT_DENSE)
+        det1 = eng.last_details(1)
+        assert np.array_equal(det1["nn_1"][0], detb["nn_1"][i]) and np.array_equal(det1["nn_2"][0], detb["nn_2"][i])
+        assert torch.equal(v1[0], vb[i]) and int(s1[0]) == int(sb[i])
+    vs, ss = eng.compute_velocity(cur, des[:1], depth, params.intrinsics(), mode=_lib.SELECT_DENSE, des_shared=True)
+    vr, sr_ = eng.compute_velocity(cur, np.repeat(des[:1], 3, 0), depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    assert torch.equal(vs, vr) and torch.equal(ss, sr_)
+
+
+def test_host_pointer_entry_point_matches_device_entry_point():
+    import ctypes as C
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
+    des, cur = synth.frame_pair(224, 20250705)
+    depth = synth.depth_pattern()
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=196).load_state_dict(sd)
+    vd, sd_ = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    K = np.array(params.intrinsics(), np.float64)
+    v = np.zeros(6, np.float64)
+    st = np.zeros(1, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = eng.lib.vitvs_compute_velocity(eng.handle, 1, p(np.ascontiguousarray(cur)), p(np.ascontiguousarray(des)), 0,
+                                        p(depth), p(K), _lib.SELECT_DENSE, None, None, p(v), p(st))
+    assert rc == 0 and int(st[0]) == int(sd_[0])
+    assert np.array_equal(v, vd.cpu().numpy()[0])

@@ -1,0 +1,503 @@
+// C ABI of libvitvs_hip.so (include/vitvs.h, include/vitvs_ops.h): handle, weights, the
+// compute_velocity path and its seams.  Host-side orchestration only; all arithmetic is in the
+// kernels (gemm.hip, attention.hip, elementwise.hip, correspond.hip, servo.hip).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vitvs.h"
+#include "../../include/vitvs_ops.h"
+#include "kernels.h"
+
+namespace vitvs {
+
+static thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    g_last_error = buf;
+    return -100 - (int)e;
+}
+
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct Block {
+    float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
+    float *qkvb = nullptr, *projb = nullptr, *fc1b = nullptr, *fc2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+    void *qkvw = nullptr, *projw = nullptr, *fc1w = nullptr, *fc2w = nullptr;
+};
+
+}  // namespace vitvs
+
+using namespace vitvs;
+
+#include <stddef.h>
+static_assert(sizeof(vitvs_config) == 96 && offsetof(vitvs_config, lambda) == 80, "vitvs_config layout is part of the ABI");
+
+struct vitvs_handle {
+    vitvs_config cfg;
+    Precision prec;
+    int device = 0;
+    int grid = 0, T = 0, N = 0, Kp = 0, Dp = 0, hidden = 0, n_img_max = 0;
+    std::string err;
+    std::vector<void*> allocs;
+    std::map<std::string, bool> have;
+    // weights
+    std::vector<Block> blk;
+    void* pe_w = nullptr;
+    float *pe_b = nullptr, *cls = nullptr, *pos = nullptr;
+    // activations
+    void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
+    float *x = nullptr, *dn = nullptr, *sq = nullptr;
+    size_t dn_elems = 0;
+    unsigned long long *row_best = nullptr, *col_best = nullptr;
+    size_t best_elems = 0;
+    // servo outputs / details
+    int32_t *nn1 = nullptr, *nn2 = nullptr, *info = nullptr, *sel_out = nullptr, *s_uv = nullptr;
+    float* sim1 = nullptr;
+    double *feat = nullptr, *Lws = nullptr;
+    int last_pairs = 0, last_T = 0;
+    // staging for the host-pointer API
+    uint8_t *st_cur = nullptr, *st_des = nullptr;
+    uint16_t* st_depth = nullptr;
+    double *st_K = nullptr, *st_vc = nullptr;
+    int32_t *st_sel = nullptr, *st_nsel = nullptr, *st_status = nullptr;
+    float* st_desc = nullptr;  // 2*T_max*Dp_max staging for vitvs_correspond
+};
+
+namespace {
+
+int set_err(vitvs_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+template <typename T>
+int dev_alloc(vitvs_handle* h, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc", __FILE__, __LINE__);
+    h->allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+}
+
+int upload_f32(vitvs_handle* h, float** dst, const float* src, size_t n) {
+    if (!*dst) {
+        int rc = dev_alloc(h, dst, n);
+        if (rc) return rc;
+    }
+    VITVS_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// matrix [rows][cols] fp32 host -> device in the handle's precision, row stride `ld` (zero padded)
+int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, size_t cols, size_t ld) {
+    const size_t es = elem_size(h->prec);
+    if (!*dst) {
+        unsigned char* p = nullptr;
+        int rc = dev_alloc(h, &p, rows * ld * es);
+        if (rc) return rc;
+        *dst = p;
+    }
+    std::vector<unsigned char> tmp(rows * ld * es, 0);
+    for (size_t r = 0; r < rows; ++r) {
+        if (h->prec == PREC_F32) {
+            memcpy(tmp.data() + r * ld * 4, src + r * cols, cols * 4);
+        } else {
+            uint16_t* d = reinterpret_cast<uint16_t*>(tmp.data()) + r * ld;
+            for (size_t c = 0; c < cols; ++c) d[c] = f32_to_bf16_host(src[r * cols + c]);
+        }
+    }
+    VITVS_HIP_CHECK(hipMemcpy(*dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int check_cfg(const vitvs_config* c, std::string& why) {
+    if (c->abi_version != VITVS_ABI_VERSION) { why = "abi_version mismatch"; return -1; }
+    if (c->dim <= 0 || c->dim % 128 != 0) { why = "dim must be a positive multiple of 128"; return -1; }
+    if (c->heads <= 0 || c->dim != c->heads * 64) { why = "dim / heads must be 64"; return -1; }
+    if (c->patch <= 0 || c->stride <= 0 || c->img_size < c->patch) { why = "bad patch/stride/img_size"; return -1; }
+    if ((c->img_size - c->patch) % c->stride != 0) { why = "img_size - patch must be a multiple of stride"; return -1; }
+    if (c->blocks <= 0) { why = "blocks must be >= 1"; return -1; }
+    if (c->precision != VITVS_F32 && c->precision != VITVS_BF16) { why = "unknown precision"; return -1; }
+    if (c->max_pairs <= 0 || c->num_pairs <= 0 || c->max_rows < c->num_pairs) { why = "bad capacity"; return -1; }
+    if (c->u_max <= 0 || c->v_max <= 0) { why = "bad camera resolution"; return -1; }
+    if (c->dim != 128 && c->dim != 256 && c->dim != 384 && c->dim != 768 && c->dim != 1024) {
+        why = "dim must be one of 128, 256, 384, 768, 1024";
+        return -1;
+    }
+    return 0;
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uint8_t* cur, hipStream_t st) {
+    const vitvs_config& c = h->cfg;
+    const int n_img = n_des + n_cur;
+    if (n_img <= 0 || n_img > h->n_img_max) return set_err(h, -3, "frame count exceeds the handle's capacity");
+    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
+    const int M = n_img * h->N, D = c.dim;
+    PatchifyArgs pa;
+    pa.des = des; pa.cur = cur; pa.n_des = n_des; pa.n_cur = n_cur;
+    pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
+    for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
+    pa.cls = h->cls; pa.pos = h->pos;
+    int rc = launch_patchify(h->prec, pa, h->Ape, h->x, st);
+    if (rc) return set_err(h, rc, "patchify launch failed");
+    rc = launch_patch_embed(h->prec, h->Ape, h->pe_w, h->pe_b, h->pos, h->x, n_img, h->T, D, h->Kp, st);
+    if (rc) return set_err(h, rc, "patch-embed launch failed");
+    for (int i = 0; i < c.blocks; ++i) {
+        const Block& b = h->blk[i];
+        rc = launch_layernorm(h->prec, h->x, b.n1w, b.n1b, h->xn, M, D, c.ln_eps, st);
+        if (!rc) rc = launch_linear(h->prec, h->xn, b.qkvw, b.qkvb, h->qkv, M, 3 * D, D, 0, st);
+        if (!rc) rc = launch_attention(h->prec, h->qkv, h->attn, n_img, h->N, c.heads, st);
+        if (!rc) rc = launch_linear_residual(h->prec, h->attn, b.projw, b.projb, b.ls1, h->x, M, D, D, st);
+        if (!rc) rc = launch_layernorm(h->prec, h->x, b.n2w, b.n2b, h->xn, M, D, c.ln_eps, st);
+        if (!rc) rc = launch_linear(h->prec, h->xn, b.fc1w, b.fc1b, h->hid, M, h->hidden, D, 1, st);
+        if (!rc) rc = launch_linear_residual(h->prec, h->hid, b.fc2w, b.fc2b, b.ls2, h->x, M, D, h->hidden, st);
+        if (rc) return set_err(h, rc, "block launch failed");
+    }
+    return 0;
+}
+
+int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const double* K, int mode,
+              const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status, hipStream_t st) {
+    const vitvs_config& c = h->cfg;
+    const int g = (int)floor(sqrt((double)T));  // reference: int(np.sqrt(T)), vitvs_v2.py:75
+    if (g * g != T) return set_err(h, -5, "token count is not a square grid");
+    if (mode < 0 || mode > 2) return set_err(h, -5, "unknown selection mode");
+    if (mode != VITVS_SELECT_DENSE && !selection) return set_err(h, -5, "selection array required for this mode");
+    if (mode == VITVS_SELECT_EXPLICIT && !n_selected) return set_err(h, -5, "n_selected required for EXPLICIT");
+    if (mode == VITVS_SELECT_DENSE && c.max_rows < T) return set_err(h, -5, "DENSE selection needs max_rows >= T");
+    ServoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = n_pairs; a.T = T; a.grid = g; a.num_pairs = c.num_pairs; a.mode = mode;
+    a.input_size = c.img_size; a.u_max = c.u_max; a.v_max = c.v_max; a.depth_h = c.v_max; a.depth_w = c.u_max;
+    const double scale = (double)c.img_size / (double)g;                 // vitvs_v2.py:511
+    a.scale_f = (float)scale; a.half_f = (float)(scale / 2.0);
+    a.scale_x = (double)c.u_max / (double)c.img_size;                    // vitvs_v2.py:544
+    a.scale_y = (double)c.v_max / (double)c.img_size;                    // vitvs_v2.py:545
+    a.K = K; a.lambda = c.lambda;
+    a.row_best = h->row_best; a.col_best = h->col_best; a.depth = Z;
+    a.selection = selection; a.n_selected = n_selected;
+    a.sel_stride = (mode == VITVS_SELECT_EXPLICIT) ? c.num_pairs : T;
+    a.v_c = v_c; a.status = status; a.nn1 = h->nn1; a.nn2 = h->nn2; a.sim1 = h->sim1; a.info = h->info;
+    a.sel_out = h->sel_out; a.s_uv = h->s_uv; a.feat = h->feat; a.L_ws = h->Lws; a.max_rows = c.max_rows;
+    h->last_pairs = n_pairs; h->last_T = T;
+    int rc = launch_servo(a, st);
+    if (rc) return set_err(h, rc, "servo launch failed (LDS budget or bad arguments)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitvs_abi_version(void) { return VITVS_ABI_VERSION; }
+
+const char* vitvs_last_error(const vitvs_handle* h) {
+    if (h && !h->err.empty()) return h->err.c_str();
+    return g_last_error.c_str();
+}
+
+int vitvs_tokens(const vitvs_handle* h) { return h ? h->T : -1; }
+int vitvs_desc_dim(const vitvs_handle* h) { return h ? h->Dp : -1; }
+
+int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
+    if (!cfg || !out) return set_err(nullptr, -1, "null argument");
+    std::string why;
+    if (check_cfg(cfg, why)) return set_err(nullptr, -1, "bad config: " + why);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return set_err(nullptr, -2, "no HIP device available");
+    vitvs_handle* h = new vitvs_handle();
+    h->cfg = *cfg;
+    h->prec = cfg->precision == VITVS_F32 ? PREC_F32 : PREC_BF16;
+    (void)hipGetDevice(&h->device);
+    h->grid = 1 + (cfg->img_size - cfg->patch) / cfg->stride;
+    h->T = h->grid * h->grid;
+    h->N = h->T + 1;
+    const int pk = 3 * cfg->patch * cfg->patch;
+    h->Kp = (pk + 63) / 64 * 64;
+    h->Dp = cfg->binned ? 9 * cfg->dim : cfg->dim;
+    h->hidden = 4 * cfg->dim;
+    h->n_img_max = 2 * cfg->max_pairs;
+    h->blk.resize(cfg->blocks);
+    const size_t M = (size_t)h->n_img_max * h->N, D = cfg->dim, es = elem_size(h->prec);
+    int rc = 0;
+    unsigned char* p8 = nullptr;
+#define ALLOC_BYTES(field, bytes) \
+    if (!rc) { rc = dev_alloc(h, &p8, (bytes)); h->field = reinterpret_cast<decltype(h->field)>(p8); }
+    ALLOC_BYTES(Ape, (size_t)h->n_img_max * h->T * h->Kp * es);
+    ALLOC_BYTES(xn, M * D * es);
+    ALLOC_BYTES(qkv, M * 3 * D * es);
+    ALLOC_BYTES(attn, M * D * es);
+    ALLOC_BYTES(hid, M * h->hidden * es);
+#undef ALLOC_BYTES
+    if (!rc) rc = dev_alloc(h, &h->x, M * D);
+    h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
+    if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
+    if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
+    h->best_elems = (size_t)cfg->max_pairs * h->T;
+    if (!rc) rc = dev_alloc(h, &h->row_best, h->best_elems);
+    if (!rc) rc = dev_alloc(h, &h->col_best, h->best_elems);
+    if (!rc) rc = dev_alloc(h, &h->nn1, h->best_elems);
+    if (!rc) rc = dev_alloc(h, &h->nn2, h->best_elems);
+    if (!rc) rc = dev_alloc(h, &h->sim1, h->best_elems);
+    const size_t P = cfg->max_pairs, R = cfg->max_rows;
+    if (!rc) rc = dev_alloc(h, &h->info, P * 8);
+    if (!rc) rc = dev_alloc(h, &h->sel_out, P * R);
+    if (!rc) rc = dev_alloc(h, &h->s_uv, P * R * 4);
+    if (!rc) rc = dev_alloc(h, &h->feat, P * R * 4);
+    if (!rc) rc = dev_alloc(h, &h->Lws, P * 7 * 2 * R);
+    const size_t img_bytes = (size_t)cfg->img_size * cfg->img_size * 3;
+    if (!rc) rc = dev_alloc(h, &h->st_cur, P * img_bytes);
+    if (!rc) rc = dev_alloc(h, &h->st_des, P * img_bytes);
+    if (!rc) rc = dev_alloc(h, &h->st_depth, P * (size_t)cfg->u_max * cfg->v_max);
+    if (!rc) rc = dev_alloc(h, &h->st_K, P * 4);
+    if (!rc) rc = dev_alloc(h, &h->st_vc, P * 6);
+    const size_t sel_cap = P * (size_t)(h->T > cfg->num_pairs ? h->T : cfg->num_pairs);
+    if (!rc) rc = dev_alloc(h, &h->st_sel, sel_cap);
+    if (!rc) rc = dev_alloc(h, &h->st_nsel, P);
+    if (!rc) rc = dev_alloc(h, &h->st_status, P);
+    if (rc) {
+        std::string msg = g_last_error;
+        vitvs_destroy(h);
+        return set_err(nullptr, rc, "allocation failed: " + msg);
+    }
+    *out = h;
+    return 0;
+}
+
+void vitvs_destroy(vitvs_handle* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64_t numel) {
+    if (!h || !name || !data) return set_err(h, -1, "null argument");
+    const vitvs_config& c = h->cfg;
+    const size_t D = c.dim, H4 = h->hidden;
+    const std::string nm(name);
+    auto want = [&](size_t n) -> int {
+        if ((size_t)numel != n) return set_err(h, -6, nm + ": expected " + std::to_string(n) + " elements, got " + std::to_string(numel));
+        return 0;
+    };
+    int rc = 0;
+    if (nm == "patch_embed.proj.weight") {
+        const size_t pk = 3 * (size_t)c.patch * c.patch;
+        if ((rc = want(D * pk))) return rc;
+        rc = upload_matrix(h, &h->pe_w, data, D, pk, h->Kp);
+    } else if (nm == "patch_embed.proj.bias") {
+        if ((rc = want(D))) return rc;
+        rc = upload_f32(h, &h->pe_b, data, D);
+    } else if (nm == "cls_token") {
+        if ((rc = want(D))) return rc;
+        rc = upload_f32(h, &h->cls, data, D);
+    } else if (nm == "pos_embed") {
+        if ((rc = want((size_t)h->N * D))) return rc;
+        rc = upload_f32(h, &h->pos, data, (size_t)h->N * D);
+    } else if (nm.rfind("blocks.", 0) == 0) {
+        const size_t dot = nm.find('.', 7);
+        if (dot == std::string::npos) return set_err(h, -6, "unknown tensor " + nm);
+        const int i = atoi(nm.substr(7, dot - 7).c_str());
+        if (i >= c.blocks) return 0;  // blocks after the descriptor layer are never run
+        if (i < 0) return set_err(h, -6, "unknown tensor " + nm);
+        Block& b = h->blk[i];
+        const std::string leaf = nm.substr(dot + 1);
+        if (leaf == "norm1.weight") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n1w, data, D); }
+        else if (leaf == "norm1.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n1b, data, D); }
+        else if (leaf == "norm2.weight") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n2w, data, D); }
+        else if (leaf == "norm2.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n2b, data, D); }
+        else if (leaf == "attn.qkv.weight") { if ((rc = want(3 * D * D))) return rc; rc = upload_matrix(h, &b.qkvw, data, 3 * D, D, D); }
+        else if (leaf == "attn.qkv.bias") { if ((rc = want(3 * D))) return rc; rc = upload_f32(h, &b.qkvb, data, 3 * D); }
+        else if (leaf == "attn.proj.weight") { if ((rc = want(D * D))) return rc; rc = upload_matrix(h, &b.projw, data, D, D, D); }
+        else if (leaf == "attn.proj.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.projb, data, D); }
+        else if (leaf == "mlp.fc1.weight") { if ((rc = want(H4 * D))) return rc; rc = upload_matrix(h, &b.fc1w, data, H4, D, D); }
+        else if (leaf == "mlp.fc1.bias") { if ((rc = want(H4))) return rc; rc = upload_f32(h, &b.fc1b, data, H4); }
+        else if (leaf == "mlp.fc2.weight") { if ((rc = want(D * H4))) return rc; rc = upload_matrix(h, &b.fc2w, data, D, H4, H4); }
+        else if (leaf == "mlp.fc2.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.fc2b, data, D); }
+        else if (leaf == "ls1.gamma") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.ls1, data, D); }
+        else if (leaf == "ls2.gamma") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.ls2, data, D); }
+        else return set_err(h, -6, "unknown tensor " + nm);
+    } else if (nm == "norm.weight" || nm == "norm.bias" || nm.rfind("head.", 0) == 0 || nm == "mask_token") {
+        return 0;  // final norm / head are dead work for the descriptor
+    } else {
+        return set_err(h, -6, "unknown tensor " + nm);
+    }
+    if (rc == 0) h->have[nm] = true;
+    return rc;
+}
+
+int vitvs_weights_ready(const vitvs_handle* hc) {
+    vitvs_handle* h = const_cast<vitvs_handle*>(hc);
+    if (!h) return -1;
+    std::vector<std::string> need = {"patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token", "pos_embed"};
+    static const char* leaves[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                                   "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                                   "mlp.fc2.weight", "mlp.fc2.bias"};
+    for (int i = 0; i < h->cfg.blocks; ++i) {
+        for (const char* l : leaves) need.push_back("blocks." + std::to_string(i) + "." + l);
+        if (h->cfg.layerscale) {
+            need.push_back("blocks." + std::to_string(i) + ".ls1.gamma");
+            need.push_back("blocks." + std::to_string(i) + ".ls2.gamma");
+        }
+    }
+    for (const auto& n : need)
+        if (!h->have.count(n)) {
+            h->err = "missing tensor " + n;
+            return -4;
+        }
+    return 0;
+}
+
+int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream) {
+    if (!h || !frames || !tokens) return set_err(h, -1, "null argument");
+    hipStream_t st = as_stream(stream);
+    int rc = forward(h, n_frames, frames, 0, nullptr, st);
+    if (rc) return rc;
+    VITVS_HIP_CHECK(hipMemcpyAsync(tokens, h->x, (size_t)n_frames * h->N * h->cfg.dim * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* desc, void* stream) {
+    if (!h || !frames || !desc) return set_err(h, -1, "null argument");
+    hipStream_t st = as_stream(stream);
+    int rc = forward(h, n_frames, frames, 0, nullptr, st);
+    if (rc) return rc;
+    rc = launch_descriptors(h->x, h->dn, desc, h->sq, n_frames, h->T, h->grid, h->cfg.dim, h->cfg.binned, st);
+    if (rc) return set_err(h, rc, "descriptor launch failed");
+    return 0;
+}
+
+int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* desc1, const float* desc2, int32_t* nn_1,
+                         int32_t* nn_2, float* sim_1, float* S_out, void* stream) {
+    if (!h || !desc1 || !desc2 || !nn_1 || !nn_2 || !sim_1) return set_err(h, -1, "null argument");
+    if (T <= 0 || Dp <= 0 || Dp % 32 != 0) return set_err(h, -5, "Dp must be a positive multiple of 32");
+    if ((size_t)2 * T * Dp > h->dn_elems || (size_t)T > h->best_elems)
+        return set_err(h, -3, "descriptors exceed the handle's workspace");
+    hipStream_t st = as_stream(stream);
+    int rc = launch_normalize_rows(desc1, h->dn, T, Dp, st);
+    if (!rc) rc = launch_normalize_rows(desc2, h->dn + (size_t)T * Dp, T, Dp, st);
+    if (rc) return set_err(h, rc, "normalise launch failed");
+    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)T * 8, st));
+    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)T * 8, st));
+    rc = launch_gram_argmax(h->dn, T, Dp, 1, 0, h->row_best, h->col_best, st);
+    if (!rc) rc = launch_decode_best(h->row_best, h->col_best, T, nn_1, nn_2, sim_1, st);
+    if (!rc && S_out) rc = launch_gram_dense(h->dn, T, Dp, 1, 0, S_out, st);
+    if (rc) return set_err(h, rc, "correspondence launch failed");
+    return 0;
+}
+
+int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, const int32_t* nn_2, const float* sim_1,
+                            const uint16_t* Z_mm, const double* K, int32_t select_mode, const int32_t* selection,
+                            int32_t n_selected, double* v_c, int32_t* status, void* stream) {
+    if (!h || !nn_1 || !nn_2 || !sim_1 || !K || !v_c || !status) return set_err(h, -1, "null argument");
+    if ((size_t)T > h->best_elems) return set_err(h, -3, "T exceeds the handle's workspace");
+    hipStream_t st = as_stream(stream);
+    int rc = launch_encode_best(nn_1, nn_2, sim_1, T, h->row_best, h->col_best, st);
+    if (rc) return set_err(h, rc, "encode launch failed");
+    VITVS_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->st_nsel), n_selected, 1, st));
+    return run_servo(h, 1, T, Z_mm, K, select_mode, selection, h->st_nsel, v_c, status, st);
+}
+
+int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
+                               int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
+                               const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
+                               void* stream) {
+    if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
+    if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
+    hipStream_t st = as_stream(stream);
+    const int n_des = des_shared ? 1 : n_pairs;
+    int rc = forward(h, n_des, I_des, n_pairs, I_cur, st);
+    if (rc) return rc;
+    rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st);
+    if (rc) return set_err(h, rc, "descriptor launch failed");
+    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)n_pairs * h->T * 8, st));
+    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)n_pairs * h->T * 8, st));
+    rc = launch_gram_argmax(h->dn, h->T, h->Dp, n_pairs, des_shared ? 1 : 0, h->row_best, h->col_best, st);
+    if (rc) return set_err(h, rc, "gram launch failed");
+    return run_servo(h, n_pairs, h->T, Z_mm, K, select_mode, selection, n_selected, v_c, status, st);
+}
+
+int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
+                           int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
+                           const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status) {
+    if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
+    if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
+    const vitvs_config& c = h->cfg;
+    const size_t img = (size_t)c.img_size * c.img_size * 3;
+    hipStream_t st = nullptr;
+    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_cur, I_cur, n_pairs * img, hipMemcpyHostToDevice, st));
+    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, (des_shared ? 1 : n_pairs) * img, hipMemcpyHostToDevice, st));
+    if (Z_mm)
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_depth, Z_mm, (size_t)n_pairs * c.u_max * c.v_max * 2, hipMemcpyHostToDevice, st));
+    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_K, K, (size_t)n_pairs * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (select_mode == VITVS_SELECT_EXPLICIT) {
+        if (!selection || !n_selected) return set_err(h, -5, "EXPLICIT selection needs ids and counts");
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * c.num_pairs * 4, hipMemcpyHostToDevice, st));
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, n_selected, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
+    } else if (select_mode == VITVS_SELECT_ORDER) {
+        if (!selection) return set_err(h, -5, "ORDER selection needs a visiting order");
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * h->T * 4, hipMemcpyHostToDevice, st));
+    }
+    int rc = vitvs_compute_velocity_dev(h, n_pairs, h->st_cur, h->st_des, des_shared, Z_mm ? h->st_depth : nullptr,
+                                        h->st_K, select_mode, h->st_sel, h->st_nsel, h->st_vc, h->st_status, st);
+    if (rc) return rc;
+    VITVS_HIP_CHECK(hipMemcpyAsync(v_c, h->st_vc, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VITVS_HIP_CHECK(hipMemcpyAsync(status, h->st_status, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    VITVS_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,
+                       int32_t* selected, int32_t* s_uv, double* feat, double* L) {
+    if (!h) return set_err(h, -1, "null argument");
+    if (n_pairs <= 0 || n_pairs > h->last_pairs) return set_err(h, -3, "no such pairs in the last call");
+    VITVS_HIP_CHECK(hipDeviceSynchronize());
+    const size_t T = h->last_T, R = h->cfg.max_rows, P = n_pairs;
+    if (nn_1) VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
+    if (nn_2) VITVS_HIP_CHECK(hipMemcpy(nn_2, h->nn2, P * T * 4, hipMemcpyDeviceToHost));
+    if (sim_1) VITVS_HIP_CHECK(hipMemcpy(sim_1, h->sim1, P * T * 4, hipMemcpyDeviceToHost));
+    if (info) VITVS_HIP_CHECK(hipMemcpy(info, h->info, P * 8 * 4, hipMemcpyDeviceToHost));
+    if (selected) VITVS_HIP_CHECK(hipMemcpy(selected, h->sel_out, P * R * 4, hipMemcpyDeviceToHost));
+    if (s_uv) VITVS_HIP_CHECK(hipMemcpy(s_uv, h->s_uv, P * R * 4 * 4, hipMemcpyDeviceToHost));
+    if (feat) VITVS_HIP_CHECK(hipMemcpy(feat, h->feat, P * R * 4 * 8, hipMemcpyDeviceToHost));
+    if (L) VITVS_HIP_CHECK(hipMemcpy(L, h->Lws, P * 7 * 2 * R * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- include/vitvs_ops.h: single-operator entry points for the kernel-level parity tests ----
+int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float* bias, void* out, int32_t M,
+                    int32_t N, int32_t K, int32_t gelu, void* stream) {
+    return launch_linear(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, bias, out, M, N, K, gelu, as_stream(stream));
+}
+int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
+                             float* x, int32_t M, int32_t N, int32_t K, void* stream) {
+    return launch_linear_residual(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, bias, ls, x, M, N, K, as_stream(stream));
+}
+int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
+                       int32_t D, float eps, void* stream) {
+    return launch_layernorm(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, x, gamma, beta, out, M, D, eps, as_stream(stream));
+}
+int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
+                       void* stream) {
+    return launch_attention(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, qkv, out, n_img, N, H, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// Multi-head self-attention (head dim 64) for the ViT blocks, flash-style: one workgroup owns
+// 64 queries of one (image, head) and streams the keys/values in tiles of 64 through LDS with an
+// online softmax, so the N x N score matrix never exists in memory (N = 197 ... 3137).
+//
+// Reference arithmetic being replaced: dino_patch/attention.py:70-80
+//   q,k,v = qkv(x).reshape(B,N,3,H,hd) ; softmax(q k^T * hd^-0.5) v ; heads re-interleaved to [B,N,C].
+//
+// Orientation (both precisions): the score tile is computed TRANSPOSED, S^T = K Q^T, so that after
+// the MFMA a lane holds 16 keys of ONE query (q = lane & 15): the softmax statistics are per-lane
+// scalars, P stays in registers as the B operand of O^T = V^T P^T, and the O^T accumulator again has
+// its query on the lane, so the running rescale is a per-lane multiply.  The MFMA k-slot -> key map
+// is permuted the same way for P and V (any bijection is legal as long as both operands agree).
+#include "common.h"
+#include "kernels.h"
+
+namespace vitvs {
+
+constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * log2(e), hd = 64
+
+// ------------------------------------------------------------------------------------ bf16
+__global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                             int N, int D) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 128];
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = smem + 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const size_t ld = (size_t)3 * D;
+    const bf16* base = qkv + (size_t)img * N * ld + h * 64;
+    const bf16* Kp = base + D;
+    const bf16* Vp = base + 2 * D;
+
+    const int q = q0 + 16 * wave + qi;
+    const int qrow = min(q, N - 1);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ld + 32 * s + 8 * g));
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int srow = tid >> 3, schunk = tid & 7;
+    u32x4 rk[2], rv[2];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(kb + srow + 32 * i, N - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)key * ld + schunk * 8);
+            rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)key * ld + schunk * 8);
+        }
+    };
+    const int ntiles = (N + 63) / 64;
+    gload(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kb = t * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(ldsK + tile128_off(srow + 32 * i, schunk)) = rk[i];
+            *reinterpret_cast<u32x4*>(ldsV + (srow + 32 * i) * 128 + schunk * 16) = rv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) gload(kb + 64);
+
+        // S^T tiles: acc_s[t4][r] = S[key = kb + 16*t4 + 4g + r][q]
+        f32x4 acc_s[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
+                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc_s[t4], 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + 16 * t4 + 4 * g + r;
+                float x = acc_s[t4][r] * kScaleLog2e;
+                x = (key < N) ? x : -INFINITY;
+                acc_s[t4][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, WAVE));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, WAVE));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(acc_s[t4][r] - m_new);
+                acc_s[t4][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+
+        // O^T += V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                // hardware-transposed LDS read: lane i of the 16-lane group gets column d0+i of 4 key rows
+                const int k0 = 32 * u + 4 * g;
+                const unsigned char* a0 = ldsV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
+                const unsigned char* a1 = a0 + 16 * 128;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, WAVE);
+    l_run += __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.0f / l_run;
+    if (q < N) {
+        bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            bf16x4 o = {(bf16)(acc_o[td][0] * inv), (bf16)(acc_o[td][1] * inv), (bf16)(acc_o[td][2] * inv),
+                        (bf16)(acc_o[td][3] * inv)};
+            *reinterpret_cast<bf16x4*>(dst + 16 * td) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ fp32
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int N, int D) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 256];
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = smem + 64 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)img * N * ld + h * 64;
+    const float* Kp = base + D;
+    const float* Vp = base + 2 * D;
+
+    const int q = q0 + 16 * wave + qi;
+    const int qrow = min(q, N - 1);
+    float4 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + 16 * c + 4 * g);
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int srow = tid >> 4, schunk = tid & 15;
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = min(kb + srow + 16 * i, N - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)key * ld + schunk * 4);
+            rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)key * ld + schunk * 4);
+        }
+    };
+    const int ntiles = (N + 63) / 64;
+    gload(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kb = t * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(ldsK + tile256_off(srow + 16 * i, schunk)) = rk[i];
+            *reinterpret_cast<u32x4*>(ldsV + tile256_off(srow + 16 * i, schunk)) = rv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) gload(kb + 64);
+
+        f32x4 acc_s[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 kf = *reinterpret_cast<const float4*>(ldsK + tile256_off(16 * t4 + qi, 4 * c + g));
+                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, acc_s[t4], 0, 0, 0);
+                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, acc_s[t4], 0, 0, 0);
+                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, acc_s[t4], 0, 0, 0);
+                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, acc_s[t4], 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + 16 * t4 + 4 * g + r;
+                float x = acc_s[t4][r] * kScaleLog2e;
+                x = (key < N) ? x : -INFINITY;
+                acc_s[t4][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, WAVE));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, WAVE));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(acc_s[t4][r] - m_new);
+                acc_s[t4][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+
+        // O^T += V^T P^T ; MFMA step (t4, r): k-slot g  <->  key 16*t4 + 4g + r
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t4 + 4 * g + r;
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    const float v = *reinterpret_cast<const float*>(ldsV + tile256_off(key, 4 * td + (qi >> 2)) +
+                                                                    (qi & 3) * 4);
+                    acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, acc_s[t4][r], acc_o[td], 0, 0, 0);
+                }
+            }
+    }
+    l_run += __shfl_xor(l_run, 16, WAVE);
+    l_run += __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.0f / l_run;
+    if (q < N) {
+        float* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
+#pragma unroll
+        for (int td = 0; td < 4; ++td)
+            *reinterpret_cast<float4*>(dst + 16 * td) =
+                make_float4(acc_o[td][0] * inv, acc_o[td][1] * inv, acc_o[td][2] * inv, acc_o[td][3] * inv);
+    }
+}
+
+int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
+    if (n_img <= 0 || N <= 0 || H <= 0) return -2;
+    const int D = H * 64;
+    dim3 grid((N + 63) / 64, H, n_img), block(256);
+    if (p == PREC_F32)
+        hipLaunchKernelGGL(attention_f32_kernel, grid, block, 0, stream, (const float*)qkv, (float*)out, N, D);
+    else
+        hipLaunchKernelGGL(attention_bf16_kernel, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, N, D);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace vitvs

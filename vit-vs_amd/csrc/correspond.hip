@@ -1,0 +1,152 @@
+// Dense token correspondence: cosine-similarity Gram of the (already L2-normalised) descriptors
+// of the desired and the current frame, fused with the row/column max+argmax, so the T x T
+// similarity matrix is never written to HBM (it is 39 MB at T = 3136).
+//
+// Reference arithmetic being replaced (vitvs_v2.py):
+//   chunk_cosine_sim            :49-56   S[i][j] = <d1_i/|d1_i|, d2_j/|d2_j|>   (python loop over T tokens)
+//   sim_1, nn_1 = max(S, -1)    :80      best current-frame token for every desired-frame token
+//   sim_2, nn_2 = max(S, -2)    :81      and the reverse; first index on ties
+// The arithmetic is exact fp32 on the f32 MFMA (v_mfma_f32_16x16x4_f32) in every precision mode.
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vitvs {
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gram_argmax_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
+                                                          int des_shared, unsigned long long* __restrict__ row_best,
+                                                          unsigned long long* __restrict__ col_best) {
+    using Tile = GemmTile<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    const int n_des = des_shared ? 1 : n_pairs;
+    const float* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;   // desired frame tokens (rows i)
+    const float* d2 = dn + (size_t)(n_des + b) * T * Dp;            // current frame tokens (cols j)
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    f32x4 acc[Tile::NT][Tile::MT];
+    gemm_mainloop<float, BM, BN>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    unsigned long long* rb = row_best + (size_t)b * T;
+    unsigned long long* cb = col_best + (size_t)b * T;
+
+    // row best (over j) for i = m: lane-local over (ni, reg), then across the 4 k-groups of lanes
+#pragma unroll
+    for (int mi = 0; mi < Tile::MT; ++mi) {
+        const int i = i0 + wm * Tile::WM + mi * 16 + (lane & 15);
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4) + r;
+                const unsigned long long k = (j < T) ? pack_best(acc[ni][mi][r], (unsigned)j) : 0ull;
+                key = (k > key) ? k : key;
+            }
+        unsigned long long o = shfl_xor_u64(key, 16);
+        key = (o > key) ? o : key;
+        o = shfl_xor_u64(key, 32);
+        key = (o > key) ? o : key;
+        if ((lane >> 4) == 0 && i < T) atomicMax(rb + i, key);
+    }
+    // column best (over i) for j = n: lane-local over mi, then across the 16 lanes of a k-group
+#pragma unroll
+    for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4) + r;
+            unsigned long long key = 0ull;
+#pragma unroll
+            for (int mi = 0; mi < Tile::MT; ++mi) {
+                const int i = i0 + wm * Tile::WM + mi * 16 + (lane & 15);
+                const unsigned long long k = (i < T) ? pack_best(acc[ni][mi][r], (unsigned)i) : 0ull;
+                key = (k > key) ? k : key;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const unsigned long long k = shfl_xor_u64(key, o);
+                key = (k > key) ? k : key;
+            }
+            if ((lane & 15) == 0 && j < T) atomicMax(cb + j, key);
+        }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gram_dense_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
+                                                         int des_shared, float* __restrict__ S) {
+    using Tile = GemmTile<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.z;
+    const int n_des = des_shared ? 1 : n_pairs;
+    const float* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;
+    const float* d2 = dn + (size_t)(n_des + b) * T * Dp;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    f32x4 acc[Tile::NT][Tile::MT];
+    gemm_mainloop<float, BM, BN>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    float* out = S + (size_t)b * T * T;
+#pragma unroll
+    for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < Tile::MT; ++mi) {
+            const int i = i0 + wm * Tile::WM + mi * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4) + r;
+                if (i < T && j < T) out[(size_t)i * T + j] = acc[ni][mi][r];
+            }
+        }
+}
+
+__global__ void decode_best_kernel(const unsigned long long* __restrict__ rb, const unsigned long long* __restrict__ cb,
+                                   int T, int32_t* nn1, int32_t* nn2, float* sim1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    nn1[i] = (int32_t)best_index(rb[i]);
+    sim1[i] = best_value(rb[i]);
+    nn2[i] = (int32_t)best_index(cb[i]);
+}
+
+__global__ void encode_best_kernel(const int32_t* __restrict__ nn1, const int32_t* __restrict__ nn2,
+                                   const float* __restrict__ sim1, int T, unsigned long long* rb,
+                                   unsigned long long* cb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    rb[i] = pack_best(sim1[i], (unsigned)nn1[i]);
+    cb[i] = pack_best(0.f, (unsigned)nn2[i]);
+}
+
+int launch_decode_best(const unsigned long long* row_best, const unsigned long long* col_best, int T, int32_t* nn1,
+                       int32_t* nn2, float* sim1, hipStream_t stream) {
+    hipLaunchKernelGGL(decode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, row_best, col_best, T, nn1, nn2,
+                       sim1);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_encode_best(const int32_t* nn1, const int32_t* nn2, const float* sim1, int T, unsigned long long* row_best,
+                       unsigned long long* col_best, hipStream_t stream) {
+    hipLaunchKernelGGL(encode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, nn1, nn2, sim1, T, row_best,
+                       col_best);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
+                       unsigned long long* col_best, hipStream_t stream) {
+    if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
+    dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
+    constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
+    gram_argmax_kernel<64, 64><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, row_best, col_best);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream) {
+    if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
+    dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
+    constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
+    gram_dense_kernel<64, 64><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, S);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace vitvs

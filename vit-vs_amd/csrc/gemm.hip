@@ -1,0 +1,146 @@
+// Linear layers of the ViT forward on the gfx950 matrix cores (see gemm_core.h for the tile loop).
+// Reference arithmetic being replaced (stock PyTorch ops issued by the reference):
+//   qkv / proj Linear     dino_patch/attention.py:72, 79
+//   fc1 -> GELU -> fc2     dino_patch/block.py:78-84 (Mlp, nn.GELU = erf form)
+//   residual + LayerScale  dino_patch/block.py:90-96, 112-115
+//   patch-embed Conv2d     dinov2_extractor.py:141, 259 (k = p, stride) as an im2col GEMM
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vitvs {
+
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, f32x4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* dst, f32x4 v) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
+    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(dst) = h;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <typename T>
+struct EpiStore {
+    T* out;
+    const float* bias;
+    int ldo;
+    int gelu;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        }
+        store4<T>(out + (size_t)m * ldo + n, v);
+    }
+};
+
+struct EpiResidual {
+    float* x;
+    const float* bias;
+    const float* ls;  // may be null
+    int ld;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        if (ls) {
+            const float4 g = *reinterpret_cast<const float4*>(ls + n);
+            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+        }
+        float4* p = reinterpret_cast<float4*>(x + (size_t)m * ld + n);
+        float4 r = *p;
+        r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+        *p = r;
+    }
+};
+
+struct EpiPatch {
+    float* x;
+    const float* bias;
+    const float* pos;
+    int T, D;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        const int img = m / T, t = m - img * T;
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n);
+        float4 r = make_float4(v[0] + b.x + pe.x, v[1] + b.y + pe.y, v[2] + b.z + pe.z, v[3] + b.w + pe.w);
+        *reinterpret_cast<float4*>(x + ((size_t)img * (T + 1) + 1 + t) * D + n) = r;
+    }
+};
+
+template <typename T, int BM, int BN, class Epi>
+__global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, int M, int N,
+                                                     int K, Epi epi) {
+    using Tile = GemmTile<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x4 acc[Tile::NT][Tile::MT];
+    gemm_mainloop<T, BM, BN>(A, W, K, K, M, N, m0, n0, 0, K, smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+    for (int ni = 0; ni < Tile::NT; ++ni) {
+        const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int mi = 0; mi < Tile::MT; ++mi) {
+            const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
+            if (m < M && n < N) epi(m, n, acc[ni][mi]);
+        }
+    }
+}
+
+static bool shapes_ok(Precision p, int M, int N, int K) {
+    const int bk = (p == PREC_F32) ? 32 : 64;
+    return M > 0 && N > 0 && K > 0 && (K % bk) == 0 && (N % 64) == 0;
+}
+
+template <typename T, class Epi>
+static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream) {
+    const int mt = (M + 63) / 64;
+    // Wide tiles halve the re-reads of A; use them only when they still fill the chip.
+    if ((N % 128) == 0 && (long)mt * (N / 128) >= 224) {
+        dim3 grid(N / 128, mt);
+        constexpr int lds = GemmTile<64, 128>::LDS_BYTES;
+        linear_kernel<T, 64, 128, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
+    } else {
+        dim3 grid(N / 64, mt);
+        constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
+        linear_kernel<T, 64, 64, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                  int gelu, hipStream_t stream) {
+    if (!shapes_ok(p, M, N, K)) return -2;
+    if (p == PREC_F32) {
+        EpiStore<float> e{(float*)out, bias, N, gelu};
+        return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream);
+    }
+    EpiStore<bf16> e{(bf16*)out, bias, N, gelu};
+    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+}
+
+int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
+                           int M, int N, int K, hipStream_t stream) {
+    if (!shapes_ok(p, M, N, K)) return -2;
+    EpiResidual e{x, bias, ls, N};
+    if (p == PREC_F32) return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream);
+    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+}
+
+int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
+                       int n_img, int T, int D, int Kp, hipStream_t stream) {
+    const int M = n_img * T;
+    if (!shapes_ok(p, M, D, Kp)) return -2;
+    EpiPatch e{x, bias, pos, T, D};
+    if (p == PREC_F32) return launch_tiles<float>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
+    return launch_tiles<bf16>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
+}
+
+}  // namespace vitvs

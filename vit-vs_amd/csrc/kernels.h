@@ -1,0 +1,112 @@
+// Internal launch interface between the C-ABI layer (api.cpp) and the HIP kernels.
+// All pointers are device pointers; every launch is asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vitvs {
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define VITVS_HIP_CHECK(expr)                                                          \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) return ::vitvs::fail_hip(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
+
+inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
+
+// ---- gemm.hip ------------------------------------------------------------------------------
+// out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]); A, W, out in precision p; gelu: erf GELU.
+int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                  int gelu, hipStream_t stream);
+// x[m][n] += ls[n] * (sum_k A[m][k] W[n][k] + bias[n]); x fp32 residual stream, ls may be null.
+int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
+                           int M, int N, int K, hipStream_t stream);
+// x[img*(T+1) + 1 + t][n] = sum_k Ape[img*T + t][k] Wpe[n][k] + bias[n] + pos[1 + t][n]
+int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
+                       int n_img, int T, int D, int Kp, hipStream_t stream);
+
+// ---- elementwise.hip -----------------------------------------------------------------------
+struct PatchifyArgs {
+    const uint8_t* des;   // [n_des][S][S][3] RGB u8
+    const uint8_t* cur;   // [n_cur][S][S][3]
+    int n_des, n_cur;
+    int S, patch, stride, grid, Kp, D;
+    float mean[3], std[3];
+    const float* cls;     // [D]
+    const float* pos;     // [1+T][D]
+};
+// Ape[(img*T + t)][k] = ((u8/255) - mean_c)/std_c for k = c*p*p + py*p + px (zero for k >= 3p²);
+// x[img*(T+1)][:] = cls + pos[0].
+int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hipStream_t stream);
+// out[m][:] = LayerNorm(x[m][:]) * gamma + beta, out in precision p.
+int launch_layernorm(Precision p, const float* x, const float* gamma, const float* beta, void* out, int M, int D,
+                     float eps, hipStream_t stream);
+// Descriptors for the correspondence stage, fp32, L2-normalised with max(|x|,1e-8):
+//   plain : dn[img][t][D]   = x[img][1+t][:] / max(norm, eps)
+//   binned: dn[img][t][9D]  = 3x3 replicate-clamped neighbourhood concat, then normalised.
+// raw (optional, may be null): the un-normalised descriptor in the same layout.
+int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
+                       int binned, hipStream_t stream);
+
+// dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
+int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);
+
+// ---- attention.hip -------------------------------------------------------------------------
+// out[img*N + q][h*64 + d] = softmax_k(q.k * 64^-0.5) v ; qkv [n_img*N][3*D] in precision p.
+int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream);
+
+// ---- correspond.hip ------------------------------------------------------------------------
+// For pair b: S = dn[a_img(b)] . dn[b_img(b)]^T (T x T, fp32); row_best[b][i] / col_best[b][j] receive
+// the packed (max similarity, first index) keys (common.h pack_best).  Buffers must be zeroed first.
+int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shared,
+                       unsigned long long* row_best, unsigned long long* col_best, hipStream_t stream);
+// Optional dense similarity matrix (tests / debugging): S[b][i][j].
+int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream);
+
+// packed keys <-> (nn_1, sim_1, nn_2) tables for the standalone correspondence / servo entry points
+int launch_decode_best(const unsigned long long* row_best, const unsigned long long* col_best, int T, int32_t* nn1,
+                       int32_t* nn2, float* sim1, hipStream_t stream);
+int launch_encode_best(const int32_t* nn1, const int32_t* nn2, const float* sim1, int T, unsigned long long* row_best,
+                       unsigned long long* col_best, hipStream_t stream);
+
+// ---- servo.hip -----------------------------------------------------------------------------
+enum SelectMode : int { SEL_EXPLICIT = 0, SEL_PRIORITY = 1, SEL_DENSE = 2 };
+enum Status : int { ST_OK = 0, ST_NO_CORRESPONDENCE = 1, ST_TOO_FEW = 2, ST_NO_DEPTH = 3 };
+
+struct ServoArgs {
+    int n_pairs, T, grid;
+    int num_pairs;            // K rows pairs of the control law (reference num_pairs)
+    int mode;                 // SelectMode
+    int input_size;           // S
+    int u_max, v_max;
+    int depth_h, depth_w;
+    float scale_f, half_f;    // fp32 patch-centre arithmetic (reference: vitvs_v2.py:511-513)
+    double scale_x, scale_y;  // camera / ViT resolution ratios (vitvs_v2.py:544-545)
+    const double* K;          // device [n_pairs][4] fx, fy, cx, cy
+    double lambda;
+    const unsigned long long* row_best;  // [n_pairs][T]
+    const unsigned long long* col_best;  // [n_pairs][T]
+    const uint16_t* depth;    // [n_pairs][depth_h][depth_w] mm, may be null -> ST_NO_DEPTH
+    const int32_t* selection; // EXPLICIT: [n_pairs][sel_stride] token ids; PRIORITY: [n_pairs][T] priorities
+    const int32_t* n_selected;// EXPLICIT: [n_pairs] count of ids (<= num_pairs)
+    int sel_stride;
+    // outputs
+    double* v_c;              // [n_pairs][6]
+    int32_t* status;          // [n_pairs]
+    int32_t* nn1;             // [n_pairs][T]
+    int32_t* nn2;             // [n_pairs][T]
+    float* sim1;              // [n_pairs][T]
+    int32_t* info;            // [n_pairs][8]: n_mutual, n_rows_pairs, same_image, n_matched, sweeps, ...
+    int32_t* sel_out;         // [n_pairs][max_rows] selected token ids (image 1)
+    int32_t* s_uv;            // [n_pairs][max_rows][4]: u*, v*, u, v
+    double* feat;             // [n_pairs][max_rows][4]: Z, x, y, sim
+    double* L_ws;             // [n_pairs][7][rows_cap] workspace (L columns + e), also an output for tests
+    int max_rows;             // capacity in feature pairs (>= num_pairs; >= T for DENSE)
+};
+int launch_servo(const ServoArgs& a, hipStream_t stream);
+
+}  // namespace vitvs

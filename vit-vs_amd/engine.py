@@ -1,0 +1,251 @@
+"""Handle to the HIP hot path (libvitvs_hip.so) for one extractor configuration on one GPU.
+
+PyTorch is used here only as plumbing: device buffers (``tensor.data_ptr()``), the current HIP
+stream, and host-side weight preparation.  All arithmetic of the path runs in the HIP kernels
+behind the C ABI (include/vitvs.h); nothing here falls back to torch ops or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ServoParams, ViTConfig
+from .weights import check_state_dict, resample_pos_embed
+
+
+class VitvsError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """One ``vitvs_handle``: device weights + workspaces for up to ``max_pairs`` frame pairs."""
+
+    def __init__(self, cfg: ViTConfig, params: ServoParams = None, *, precision: str = "fp32", max_pairs: int = 1,
+                 max_rows: Optional[int] = None, binned: Optional[bool] = None, device=None):
+        if not torch.cuda.is_available():
+            raise VitvsError("no HIP device: the ViT-VS hot path has no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.params = params or ServoParams(dino_input_size=cfg.img_size)
+        self.precision = {"fp32": _lib.F32, "f32": _lib.F32, "bf16": _lib.BF16}[precision]
+        self.precision_name = "fp32" if self.precision == _lib.F32 else "bf16"
+        self.binned = self.params.use_feature_binning if binned is None else bool(binned)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_pairs = int(max_pairs)
+        self.max_rows = int(max_rows) if max_rows is not None else int(self.params.num_pairs)
+        c = _lib.VitvsConfig()
+        c.abi_version = _lib.ABI_VERSION
+        c.img_size, c.patch, c.stride, c.dim = cfg.img_size, cfg.patch, cfg.stride, cfg.dim
+        c.heads, c.blocks, c.layerscale = cfg.heads, cfg.blocks_run, int(cfg.layerscale)
+        for i in range(3):
+            c.mean[i] = cfg.mean[i]
+            c.std[i] = cfg.std[i]
+        c.ln_eps = cfg.ln_eps
+        c.precision = self.precision
+        c.binned = int(self.binned)
+        c.num_pairs = self.params.num_pairs
+        c.u_max, c.v_max = self.params.u_max, self.params.v_max
+        c.lambda_ = self.params.lambda_
+        c.max_pairs, c.max_rows = self.max_pairs, self.max_rows
+        self._c = c
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.vitvs_create(C.byref(c), C.byref(self.handle))
+        if rc != 0:
+            raise VitvsError(f"vitvs_create failed ({rc}): {_lib.last_error(None)}")
+        self.tokens = self.lib.vitvs_tokens(self.handle)
+        self.desc_dim = self.lib.vitvs_desc_dim(self.handle)
+        assert self.tokens == cfg.tokens
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.vitvs_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            raise VitvsError(f"{what} failed ({rc}): {_lib.last_error(self.handle)}")
+        return rc
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> "Engine":
+        """Upload a DINO / timm / DINOv2 state dict (fp32).  ``pos_embed`` is resampled to this
+        handle's token grid on the host first (reference: dinov2_extractor.py:94-118)."""
+        check_state_dict(self.cfg, sd)
+        for name, t in sd.items():
+            if name == "pos_embed":
+                t = resample_pos_embed(t, self.cfg.grid)
+            elif name.startswith("blocks."):
+                if int(name.split(".")[1]) >= self.cfg.blocks_run:
+                    continue
+            elif name not in ("patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token"):
+                continue
+            a = np.ascontiguousarray(t.detach().to(torch.float32).cpu().numpy())
+            rc = self.lib.vitvs_set_tensor(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p), a.size)
+            self._check(rc, f"vitvs_set_tensor({name})")
+        self._check(self.lib.vitvs_weights_ready(self.handle), "vitvs_weights_ready")
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    def _frames(self, frames) -> torch.Tensor:
+        t = torch.as_tensor(frames)
+        if t.dtype != torch.uint8:
+            raise VitvsError("frames must be uint8 RGB, HWC")
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        s = self.cfg.img_size
+        if tuple(t.shape[1:]) != (s, s, 3):
+            raise VitvsError(f"frames must be [n,{s},{s},3], got {tuple(t.shape)}")
+        return t.to(self.device).contiguous()
+
+    # ------------------------------------------------------------------ seams
+    def forward_tokens(self, frames) -> torch.Tensor:
+        """Residual stream after block ``layer``: float32 [n, 1+T, D] (the hooked tensor,
+        reference: dinov2_extractor.py:198-199)."""
+        f = self._frames(frames)
+        n = f.shape[0]
+        out = torch.empty((n, self.cfg.seq, self.cfg.dim), dtype=torch.float32, device=self.device)
+        rc = self.lib.vitvs_forward_tokens_dev(self.handle, n, _ptr(f), _ptr(out), _stream_ptr(self.device))
+        self._check(rc, "vitvs_forward_tokens_dev")
+        return out
+
+    def extract_descriptors(self, frames) -> torch.Tensor:
+        """``ViTExtractor.extract_descriptors(..., facet='token', bin=binned)``: [n,1,T,D']."""
+        f = self._frames(frames)
+        n = f.shape[0]
+        out = torch.empty((n, 1, self.tokens, self.desc_dim), dtype=torch.float32, device=self.device)
+        rc = self.lib.vitvs_extract_descriptors_dev(self.handle, n, _ptr(f), _ptr(out), _stream_ptr(self.device))
+        self._check(rc, "vitvs_extract_descriptors_dev")
+        return out
+
+    def correspond(self, desc1: torch.Tensor, desc2: torch.Tensor, want_matrix: bool = False):
+        """Similarity + argmax stage of find_correspondences_batch on [T,D] descriptors."""
+        d1 = desc1.to(self.device, torch.float32).contiguous()
+        d2 = desc2.to(self.device, torch.float32).contiguous()
+        t, d = d1.shape
+        pad = (-d) % 32
+        if pad:  # zero columns leave cosine similarities unchanged
+            d1 = torch.nn.functional.pad(d1, (0, pad))
+            d2 = torch.nn.functional.pad(d2, (0, pad))
+        nn1 = torch.empty(t, dtype=torch.int32, device=self.device)
+        nn2 = torch.empty(t, dtype=torch.int32, device=self.device)
+        sim1 = torch.empty(t, dtype=torch.float32, device=self.device)
+        smat = torch.empty((t, t), dtype=torch.float32, device=self.device) if want_matrix else None
+        rc = self.lib.vitvs_correspond_dev(self.handle, t, d + pad, _ptr(d1), _ptr(d2), _ptr(nn1), _ptr(nn2),
+                                           _ptr(sim1), _ptr(smat), _stream_ptr(self.device))
+        self._check(rc, "vitvs_correspond_dev")
+        return (nn1, nn2, sim1, smat) if want_matrix else (nn1, nn2, sim1)
+
+    def _selection_args(self, mode, selection, n_pairs, tokens):
+        if mode == _lib.SELECT_DENSE:
+            return None, None
+        if selection is None:
+            raise VitvsError("this selection mode needs a selection array")
+        if mode == _lib.SELECT_EXPLICIT:
+            k = self.params.num_pairs
+            sel = torch.full((n_pairs, k), 0, dtype=torch.int32)
+            cnt = torch.zeros(n_pairs, dtype=torch.int32)
+            rows = selection if isinstance(selection, (list, tuple)) else [selection]
+            if len(rows) != n_pairs:
+                raise VitvsError("one id list per pair expected")
+            for b, ids in enumerate(rows):
+                ids = torch.as_tensor(ids, dtype=torch.int32).flatten()[:k]
+                sel[b, :ids.numel()] = ids
+                cnt[b] = ids.numel()
+            return sel.to(self.device), cnt.to(self.device)
+        order = torch.as_tensor(selection, dtype=torch.int32).reshape(n_pairs, tokens)
+        return order.to(self.device).contiguous(), None
+
+    def servo_from_nn(self, nn_1, nn_2, sim_1, depth, K, mode=_lib.SELECT_DENSE, selection=None):
+        """Control law on given nearest-neighbour tables (one pair)."""
+        nn1 = torch.as_tensor(nn_1).to(self.device, torch.int32).contiguous()
+        nn2 = torch.as_tensor(nn_2).to(self.device, torch.int32).contiguous()
+        s1 = torch.as_tensor(sim_1).to(self.device, torch.float32).contiguous()
+        t = nn1.numel()
+        z = None if depth is None else torch.as_tensor(depth).to(self.device).contiguous()
+        if z is not None and (z.dtype != torch.uint16 or tuple(z.shape[-2:]) != (self.params.v_max, self.params.u_max)):
+            raise VitvsError("depth must be uint16 [v_max,u_max]")
+        kk = torch.as_tensor(K, dtype=torch.float64).reshape(1, 4).to(self.device)
+        sel, cnt = self._selection_args(mode, selection, 1, t)
+        v = torch.zeros((1, 6), dtype=torch.float64, device=self.device)
+        st = torch.zeros(1, dtype=torch.int32, device=self.device)
+        n_sel = int(cnt[0].item()) if cnt is not None else 0
+        rc = self.lib.vitvs_servo_from_nn_dev(self.handle, t, _ptr(nn1), _ptr(nn2), _ptr(s1), _ptr(z), _ptr(kk), mode,
+                                              _ptr(sel), n_sel, _ptr(v), _ptr(st), _stream_ptr(self.device))
+        self._check(rc, "vitvs_servo_from_nn_dev")
+        self._last_tokens = t
+        return v[0], st[0]
+
+    # ------------------------------------------------------------------ the hot path
+    def compute_velocity_dev(self, I_cur: torch.Tensor, I_des: torch.Tensor, Z: Optional[torch.Tensor],
+                             K: torch.Tensor, mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
+                             n_selected: Optional[torch.Tensor] = None, des_shared: bool = False,
+                             out_v: Optional[torch.Tensor] = None, out_status: Optional[torch.Tensor] = None):
+        """Device-resident call: every argument is a CUDA tensor already laid out as the C ABI
+        wants it; work is enqueued on the current stream and nothing synchronises."""
+        n = I_cur.shape[0]
+        v = out_v if out_v is not None else torch.empty((n, 6), dtype=torch.float64, device=self.device)
+        st = out_status if out_status is not None else torch.empty(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.vitvs_compute_velocity_dev(self.handle, n, _ptr(I_cur), _ptr(I_des), int(des_shared), _ptr(Z),
+                                                 _ptr(K), mode, _ptr(selection), _ptr(n_selected), _ptr(v), _ptr(st),
+                                                 _stream_ptr(self.device))
+        self._check(rc, "vitvs_compute_velocity_dev")
+        self._last_tokens = self.tokens
+        return v, st
+
+    def compute_velocity(self, I_cur, I_des, Z, K, mode: int = _lib.SELECT_DENSE, selection=None,
+                         des_shared: bool = False):
+        """Convenience form: numpy / CPU inputs are moved to the device, then the device path runs."""
+        cur = self._frames(I_cur)
+        des = self._frames(I_des)
+        n = cur.shape[0]
+        if des.shape[0] != (1 if des_shared else n):
+            raise VitvsError("I_des must hold one frame per pair (or one frame when des_shared)")
+        z = None
+        if Z is not None:
+            z = torch.as_tensor(Z)
+            if z.dtype != torch.uint16:
+                raise VitvsError("Z must be the sensor's uint16 millimetre image")
+            z = z.reshape(n, self.params.v_max, self.params.u_max).to(self.device).contiguous()
+        kk = torch.as_tensor(K, dtype=torch.float64).reshape(-1, 4)
+        if kk.shape[0] == 1 and n > 1:
+            kk = kk.expand(n, 4)
+        kk = kk.contiguous().to(self.device)
+        sel, cnt = self._selection_args(mode, selection, n, self.tokens)
+        return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared)
+
+    def last_details(self, n_pairs: int = 1) -> dict:
+        """Host copies of what the last servo call left on the device (synchronises)."""
+        t, r = getattr(self, "_last_tokens", self.tokens), self.max_rows
+        nn1 = np.empty((n_pairs, t), np.int32)
+        nn2 = np.empty((n_pairs, t), np.int32)
+        sim1 = np.empty((n_pairs, t), np.float32)
+        info = np.empty((n_pairs, 8), np.int32)
+        sel = np.empty((n_pairs, r), np.int32)
+        suv = np.empty((n_pairs, r, 4), np.int32)
+        feat = np.empty((n_pairs, r, 4), np.float64)
+        L = np.empty((n_pairs, 7, 2 * r), np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.vitvs_last_details(self.handle, n_pairs, p(nn1), p(nn2), p(sim1), p(info), p(sel), p(suv),
+                                         p(feat), p(L))
+        self._check(rc, "vitvs_last_details")
+        return dict(nn_1=nn1, nn_2=nn2, sim_1=sim1, info=info, selected=sel, s_uv=suv, feat=feat, L=L)
