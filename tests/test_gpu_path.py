@@ -22,9 +22,9 @@ pytestmark = pytest.mark.gpu
 VC_TOL = 1e-4  # north_star: relative L2 on v_c
 
 
-def _engine(cfg, **kw):
+def _engine(cfg, params=None, **kw):
     from vitvs_amd.engine import Engine
-    return Engine(cfg, **kw)
+    return Engine(cfg, params, **kw)
 
 
 def _tiny_cfg(layerscale=False, img=64):
