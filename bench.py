@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: servo updates/sec for ViT-B/16 224x224 frame pairs (BASELINE.json configs[1]).
+
+One "step" = one compute_velocity update per GPU: both frames forwarded through block 11 (I_des is
+recomputed, as the reference does), dense cosine correspondence, mutual-NN filter, 24 features drawn
+in a fresh random visiting order, interaction matrix, pseudo-inverse -> v_c.  Inputs (frames, depth,
+intrinsics, weights, visiting orders) are resident in HBM before the timed region; each step is
+enqueued without host synchronisation (one hipGraph replay + a 784-byte order copy), and with N > 1
+every step ends with an RCCL all-gather of the 6 doubles of v_c.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--pairs B] [--config KEY]
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel class with the largest share of the step,
+timed with HIP event pairs on the launch stream in a second, instrumented pass over the same steps
+(`value` comes from the un-instrumented pass).  `cpu_baseline` is the CPU oracle (PyTorch-CPU fp32
+forward + the reference's correspondence/control-law arithmetic) timed on this host at N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import vitvs_amd  # noqa: E402,F401
+from vitvs_amd import _lib, config, synth, weights  # noqa: E402
+from vitvs_amd import dist as vdist  # noqa: E402
+from vitvs_amd.engine import Engine  # noqa: E402
+
+PEAK_MFMA = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def kernel_work(cfg, n_img, n_pairs, es, binned):
+    """Algorithmic FLOPs and minimum HBM bytes per LAUNCH of each kernel class."""
+    n, t, d, h = cfg.seq, cfg.tokens, cfg.dim, cfg.hidden
+    m = n_img * n
+    dp = d * (9 if binned else 1)
+    kp = -(-cfg.patch_k // 64) * 64
+    return {
+        "patchify": (0.0, n_img * cfg.img_size ** 2 * 3 + n_img * t * kp * es),
+        "patch_embed": (2.0 * n_img * t * cfg.patch_k * d, n_img * t * kp * es + d * kp * es + n_img * t * d * 4),
+        "layernorm": (8.0 * m * d, m * d * (4 + es)),
+        "qkv": (2.0 * m * 3 * d * d, (m * d + 3 * d * d + m * 3 * d) * es),
+        "attention": (4.0 * n_img * n * n * d, (m * 3 * d + m * d) * es),
+        "proj": (2.0 * m * d * d, (m * d + d * d) * es + 2 * m * d * 4),
+        "fc1": (2.0 * m * h * d, (m * d + h * d + m * h) * es),
+        "fc2": (2.0 * m * d * h, (m * h + d * h) * es + 2 * m * d * 4),
+        "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),
+        "gram_argmax": (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4),
+        "servo": (0.0, n_pairs * t * 16),
+    }
+
+
+def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=20.0):
+    from oracle import servo_ref as sr
+    from oracle import vit_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    frames = np.stack([des, cur])
+
+    def update():
+        toks = vit_ref.block_tokens(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                    mean=cfg.mean, std=cfg.std)[:, 1:]
+        return sr.servo_update(toks[0], toks[1], depth, num_pairs=params.num_pairs, input_size=cfg.img_size,
+                               u_max=params.u_max, v_max=params.v_max, fx=params.f_x, fy=params.f_y,
+                               lam=params.lambda_)
+    torch.manual_seed(121)
+    for _ in range(2):
+        out = update()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        out = update()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return out, dict(value=1.0 / med, unit="updates/s", cores=torch.get_num_threads(), kind="port",
+                     sample=f"{len(times)} updates of the same ViT-B/16-class frame pair (median {med * 1e3:.1f} ms, "
+                            f"PyTorch-CPU fp32 forward + reference correspondence loop + numpy pinv)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
+    ap.add_argument("--config", default="vitb16_224", choices=sorted(config.BASELINE_CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = config.baseline_config(args.config)
+    binned = False  # north_star path: token descriptors (binning is a tested option, not the headline)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=binned)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    B = args.pairs
+    eng = Engine(cfg, params, precision=args.precision, max_pairs=B).load_state_dict(sd)
+
+    # per-rank synthetic inputs, resident in HBM
+    seed0 = synth.ACCEPTED_FRAME_SEEDS[args.config]
+    pairs = [synth.frame_pair(cfg.img_size, seed0 + 1000 * rank + i) for i in range(B)]
+    des_np = np.stack([p[0] for p in pairs])
+    cur_np = np.stack([p[1] for p in pairs])
+    depth_np = synth.depth_pattern()
+    I_des = torch.from_numpy(des_np).to(dev)
+    I_cur = torch.from_numpy(cur_np).to(dev)
+    Z = torch.from_numpy(np.stack([depth_np] * B)).to(dev)
+    K = torch.tensor([params.intrinsics()] * B, dtype=torch.float64, device=dev)
+    total = args.warmup + args.steps
+    gen = torch.Generator().manual_seed(121 + rank)
+    orders = torch.stack([torch.stack([torch.randperm(cfg.tokens, generator=gen) for _ in range(B)])
+                          for _ in range(total)]).to(torch.int32).to(dev)       # [total, B, T]
+    order_buf = torch.empty((B, cfg.tokens), dtype=torch.int32, device=dev)
+    v = torch.zeros((B, 6), dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    v_all = torch.zeros((world * B, 6), dtype=torch.float64, device=dev) if world > 1 else None
+
+    stream = torch.cuda.Stream(device=dev)
+
+    def step(i):
+        order_buf.copy_(orders[i], non_blocking=True)
+        eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, order_buf, None, False, v, status)
+        if world > 1:
+            vdist.gather_velocities(v, world * B, out=v_all)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        status_host = status.cpu().numpy().copy()
+        v_host = v.cpu().numpy().copy()
+
+        # single-update latency with a host synchronisation per update (a control loop's view)
+        lat = []
+        for i in range(10):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            step(args.warmup + i % max(args.steps, 1))
+            torch.cuda.synchronize(dev)
+            lat.append(time.perf_counter() - t1)
+
+        # instrumented pass: HIP event pairs around every launch, on the launch stream
+        eng.timing_enable(True)
+        n_prof = min(args.steps, 50)
+        for i in range(n_prof):
+            step(args.warmup + i)
+        prof = eng.timing_collect()
+        eng.timing_enable(False)
+
+    updates = world * B * args.steps
+    value = updates / elapsed
+    es = 2 if args.precision == "bf16" else 4
+    work = kernel_work(cfg, 2 * B, B, es, binned)
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt == 0:
+            continue
+        avg = ms / cnt * 1e-3
+        fl, by = work[name]
+        kernels[name] = dict(launches_per_step=cnt / n_prof, avg_us=round(avg * 1e6, 3),
+                             step_share_us=round(ms / n_prof * 1e3, 2),
+                             tflops=round(fl / avg / 1e12, 3), gbps=round(by / avg / 1e9, 1))
+    dom = max(kernels, key=lambda k: kernels[k]["step_share_us"])
+    fl, by = work[dom]
+    avg_s = kernels[dom]["avg_us"] * 1e-6
+    mfma_bound = dom in ("qkv", "proj", "fc1", "fc2", "attention", "patch_embed", "gram_argmax")
+    if mfma_bound:
+        peak = PEAK_MFMA["fp32" if dom == "gram_argmax" else args.precision]
+        roof = dict(kernel=dom, bound="mfma", achieved=round(fl / avg_s / 1e12, 3), peak=peak / 1e12, unit="TFLOP/s",
+                    frac=round(fl / avg_s / peak, 5), traffic=None,
+                    algorithmic_flops_per_launch=fl, avg_launch_us=kernels[dom]["avg_us"])
+    else:
+        roof = dict(kernel=dom, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9, unit="GB/s",
+                    frac=round(by / avg_s / PEAK_HBM, 5), traffic=None,
+                    algorithmic_bytes_per_launch=by, avg_launch_us=kernels[dom]["avg_us"])
+
+    out = dict(
+        metric="servo_updates_per_sec", value=round(value, 2), unit="updates/s", n_gpus=world, steps=args.steps,
+        warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype=args.precision, data="synthetic",
+        config=dict(workload=f"{cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair(s): both frames forwarded "
+                             f"through block {cfg.layer}, cosine correspondence, mutual-NN, {params.num_pairs} features "
+                             f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update",
+                    key=args.config, pairs_per_step_per_gpu=B, tokens=cfg.tokens, dim=cfg.dim,
+                    parallelism=f"dp{world} (frame pairs sharded, v_c all-gather per step)" if world > 1 else "single GPU",
+                    weights="synthetic seed 0", selection="ORDER"),
+        roofline=roof,
+        cpu_baseline=None,
+        path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),
+                  tflops=round(cfg.flops_per_pair(binned) * value / world / 1e12, 3),
+                  frac_of_mfma_peak=round(cfg.flops_per_pair(binned) * value / world / PEAK_MFMA[args.precision], 5),
+                  weight_bytes=cfg.weight_elems() * es,
+                  weight_stream_frac_of_hbm_peak=round(cfg.weight_elems() * es * value / world / B / PEAK_HBM, 5)),
+        latency_ms_with_host_sync=round(float(np.median(lat)) * 1e3, 4),
+        kernels=kernels,
+        status=[int(s) for s in status_host],
+        v_c=[float(x) for x in v_host[0]],
+    )
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        ref, base = cpu_baseline(cfg, sd, des_np[0], cur_np[0], depth_np, params)
+        out["cpu_baseline"] = base
+        det = eng.last_details(1)
+        if ref.get("corr") is not None:
+            out["parity"] = dict(nn_1_agreement=float((det["nn_1"][0] == ref["corr"]["nn_1"].numpy()).mean()),
+                                 nn_2_agreement=float((det["nn_2"][0] == ref["corr"]["nn_2"].numpy()).mean()),
+                                 note="GPU (this dtype) vs CPU oracle argmax on the benchmarked pair; v_c parity is "
+                                      "asserted by tests/test_gpu_path.py given identical selections")
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

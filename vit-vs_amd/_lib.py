@@ -51,6 +51,10 @@ PROTOTYPES = {
     "vitvs_correspond_dev": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vitvs_servo_from_nn_dev": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "vitvs_last_details": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vitvs_timing_enable": (_I, [_P, _I]),
+    "vitvs_timing_classes": (_I, []),
+    "vitvs_timing_class_name": (C.c_char_p, [_I]),
+    "vitvs_timing_collect": (_I, [_P, _I, _P, _P]),
     "vitvs_tokens": (_I, [_P]),
     "vitvs_desc_dim": (_I, [_P]),
     "vitvs_op_linear": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -3,6 +3,7 @@
 // kernels (gemm.hip, attention.hip, elementwise.hip, correspond.hip, servo.hip).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -73,7 +74,21 @@ struct vitvs_handle {
     uint16_t* st_depth = nullptr;
     double *st_K = nullptr, *st_vc = nullptr;
     int32_t *st_sel = nullptr, *st_nsel = nullptr, *st_status = nullptr;
-    float* st_desc = nullptr;  // 2*T_max*Dp_max staging for vitvs_correspond
+    // per-kernel-class timing (HIP events on the launch stream), see vitvs_timing_*
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;      // class of event pair i (events 2i, 2i+1)
+    size_t ev_used = 0;
+    // captured hipGraphs of compute_velocity_dev, keyed on the argument tuple
+    struct GraphEntry {
+        std::vector<uintptr_t> key;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t last_use = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    bool use_graphs = true;
 };
 
 namespace {
@@ -144,6 +159,37 @@ int check_cfg(const vitvs_config* c, std::string& why) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+enum KernelClass : int {
+    KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
+    KC_GRAM, KC_SERVO, KC_COUNT
+};
+const char* const kClassNames[KC_COUNT] = {"patchify", "patch_embed", "layernorm", "qkv", "attention", "proj",
+                                           "fc1", "fc2", "descriptors", "gram_argmax", "servo"};
+
+// Brackets one launch with a HIP event pair on its stream when timing is enabled.
+struct Span {
+    vitvs_handle* h;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    Span(vitvs_handle* h_, int cls, hipStream_t st_) : h(h_), st(st_) {
+        if (!h->timing) return;
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            h->ev_pool.push_back(a);
+            h->ev_pool.push_back(b);
+        }
+        hipEvent_t start = h->ev_pool[h->ev_used];
+        stop = h->ev_pool[h->ev_used + 1];
+        h->ev_used += 2;
+        h->ev_class.push_back(cls);
+        (void)hipEventRecord(start, st);
+    }
+    ~Span() {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
+
 int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uint8_t* cur, hipStream_t st) {
     const vitvs_config& c = h->cfg;
     const int n_img = n_des + n_cur;
@@ -155,19 +201,23 @@ int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uin
     pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
     for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
     pa.cls = h->cls; pa.pos = h->pos;
-    int rc = launch_patchify(h->prec, pa, h->Ape, h->x, st);
+    int rc;
+    { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, h->Ape, h->x, st); }
     if (rc) return set_err(h, rc, "patchify launch failed");
-    rc = launch_patch_embed(h->prec, h->Ape, h->pe_w, h->pe_b, h->pos, h->x, n_img, h->T, D, h->Kp, st);
+    { Span sp(h, KC_PATCH_EMBED, st);
+      rc = launch_patch_embed(h->prec, h->Ape, h->pe_w, h->pe_b, h->pos, h->x, n_img, h->T, D, h->Kp, st); }
     if (rc) return set_err(h, rc, "patch-embed launch failed");
     for (int i = 0; i < c.blocks; ++i) {
         const Block& b = h->blk[i];
-        rc = launch_layernorm(h->prec, h->x, b.n1w, b.n1b, h->xn, M, D, c.ln_eps, st);
-        if (!rc) rc = launch_linear(h->prec, h->xn, b.qkvw, b.qkvb, h->qkv, M, 3 * D, D, 0, st);
-        if (!rc) rc = launch_attention(h->prec, h->qkv, h->attn, n_img, h->N, c.heads, st);
-        if (!rc) rc = launch_linear_residual(h->prec, h->attn, b.projw, b.projb, b.ls1, h->x, M, D, D, st);
-        if (!rc) rc = launch_layernorm(h->prec, h->x, b.n2w, b.n2b, h->xn, M, D, c.ln_eps, st);
-        if (!rc) rc = launch_linear(h->prec, h->xn, b.fc1w, b.fc1b, h->hid, M, h->hidden, D, 1, st);
-        if (!rc) rc = launch_linear_residual(h->prec, h->hid, b.fc2w, b.fc2b, b.ls2, h->x, M, D, h->hidden, st);
+        { Span sp(h, KC_LAYERNORM, st); rc = launch_layernorm(h->prec, h->x, b.n1w, b.n1b, h->xn, M, D, c.ln_eps, st); }
+        if (!rc) { Span sp(h, KC_QKV, st); rc = launch_linear(h->prec, h->xn, b.qkvw, b.qkvb, h->qkv, M, 3 * D, D, 0, st); }
+        if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, h->qkv, h->attn, n_img, h->N, c.heads, st); }
+        if (!rc) { Span sp(h, KC_PROJ, st);
+                   rc = launch_linear_residual(h->prec, h->attn, b.projw, b.projb, b.ls1, h->x, M, D, D, st); }
+        if (!rc) { Span sp(h, KC_LAYERNORM, st); rc = launch_layernorm(h->prec, h->x, b.n2w, b.n2b, h->xn, M, D, c.ln_eps, st); }
+        if (!rc) { Span sp(h, KC_FC1, st); rc = launch_linear(h->prec, h->xn, b.fc1w, b.fc1b, h->hid, M, h->hidden, D, 1, st); }
+        if (!rc) { Span sp(h, KC_FC2, st);
+                   rc = launch_linear_residual(h->prec, h->hid, b.fc2w, b.fc2b, b.ls2, h->x, M, D, h->hidden, st); }
         if (rc) return set_err(h, rc, "block launch failed");
     }
     return 0;
@@ -197,7 +247,8 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     a.v_c = v_c; a.status = status; a.nn1 = h->nn1; a.nn2 = h->nn2; a.sim1 = h->sim1; a.info = h->info;
     a.sel_out = h->sel_out; a.s_uv = h->s_uv; a.feat = h->feat; a.L_ws = h->Lws; a.max_rows = c.max_rows;
     h->last_pairs = n_pairs; h->last_T = T;
-    int rc = launch_servo(a, st);
+    int rc;
+    { Span sp(h, KC_SERVO, st); rc = launch_servo(a, st); }
     if (rc) return set_err(h, rc, "servo launch failed (LDS budget or bad arguments)");
     return 0;
 }
@@ -236,6 +287,8 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->hidden = 4 * cfg->dim;
     h->n_img_max = 2 * cfg->max_pairs;
     h->blk.resize(cfg->blocks);
+    const char* ng = getenv("VITVS_NO_GRAPH");
+    h->use_graphs = !(ng && ng[0] == '1');
     const size_t M = (size_t)h->n_img_max * h->N, D = cfg->dim, es = elem_size(h->prec);
     int rc = 0;
     unsigned char* p8 = nullptr;
@@ -284,6 +337,11 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 
 void vitvs_destroy(vitvs_handle* h) {
     if (!h) return;
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -416,6 +474,24 @@ int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, con
     return run_servo(h, 1, T, Z_mm, K, select_mode, selection, h->st_nsel, v_c, status, st);
 }
 
+static int compute_velocity_body(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
+                                 int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
+                                 const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
+                                 hipStream_t st) {
+    const int n_des = des_shared ? 1 : n_pairs;
+    int rc = forward(h, n_des, I_des, n_pairs, I_cur, st);
+    if (rc) return rc;
+    { Span sp(h, KC_DESCRIPTORS, st);
+      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st); }
+    if (rc) return set_err(h, rc, "descriptor launch failed");
+    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)n_pairs * h->T * 8, st));
+    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)n_pairs * h->T * 8, st));
+    { Span sp(h, KC_GRAM, st);
+      rc = launch_gram_argmax(h->dn, h->T, h->Dp, n_pairs, des_shared ? 1 : 0, h->row_best, h->col_best, st); }
+    if (rc) return set_err(h, rc, "gram launch failed");
+    return run_servo(h, n_pairs, h->T, Z_mm, K, select_mode, selection, n_selected, v_c, status, st);
+}
+
 int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                                int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                                const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
@@ -423,16 +499,50 @@ int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* 
     if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
     hipStream_t st = as_stream(stream);
-    const int n_des = des_shared ? 1 : n_pairs;
-    int rc = forward(h, n_des, I_des, n_pairs, I_cur, st);
-    if (rc) return rc;
-    rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st);
-    if (rc) return set_err(h, rc, "descriptor launch failed");
-    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)n_pairs * h->T * 8, st));
-    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)n_pairs * h->T * 8, st));
-    rc = launch_gram_argmax(h->dn, h->T, h->Dp, n_pairs, des_shared ? 1 : 0, h->row_best, h->col_best, st);
-    if (rc) return set_err(h, rc, "gram launch failed");
-    return run_servo(h, n_pairs, h->T, Z_mm, K, select_mode, selection, n_selected, v_c, status, st);
+    if (!h->use_graphs || h->timing || st == nullptr)
+        return compute_velocity_body(h, n_pairs, I_cur, I_des, des_shared, Z_mm, K, select_mode, selection, n_selected,
+                                     v_c, status, st);
+    // The whole update is one hipGraph per distinct argument tuple (launch-bound chain of ~90 kernels).
+    std::vector<uintptr_t> key = {(uintptr_t)n_pairs, (uintptr_t)I_cur, (uintptr_t)I_des, (uintptr_t)des_shared,
+                                  (uintptr_t)Z_mm, (uintptr_t)K, (uintptr_t)select_mode, (uintptr_t)selection,
+                                  (uintptr_t)n_selected, (uintptr_t)v_c, (uintptr_t)status};
+    for (auto& g : h->graphs)
+        if (g.key == key) {
+            g.last_use = ++h->graph_clock;
+            h->last_pairs = n_pairs; h->last_T = h->T;
+            VITVS_HIP_CHECK(hipGraphLaunch(g.exec, st));
+            return 0;
+        }
+    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
+    VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = compute_velocity_body(h, n_pairs, I_cur, I_des, des_shared, Z_mm, K, select_mode, selection, n_selected,
+                                   v_c, status, st);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __FILE__, __LINE__);
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    if (h->graphs.size() >= 8) {  // evict the least recently used entry
+        size_t victim = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i)
+            if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
+        (void)hipGraphExecDestroy(h->graphs[victim].exec);
+        (void)hipGraphDestroy(h->graphs[victim].graph);
+        h->graphs.erase(h->graphs.begin() + victim);
+    }
+    vitvs_handle::GraphEntry ge;
+    ge.key = key; ge.graph = graph; ge.exec = exec; ge.last_use = ++h->graph_clock;
+    h->graphs.push_back(ge);
+    VITVS_HIP_CHECK(hipGraphLaunch(exec, st));
+    return 0;
 }
 
 int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
@@ -479,6 +589,34 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
     if (s_uv) VITVS_HIP_CHECK(hipMemcpy(s_uv, h->s_uv, P * R * 4 * 4, hipMemcpyDeviceToHost));
     if (feat) VITVS_HIP_CHECK(hipMemcpy(feat, h->feat, P * R * 4 * 8, hipMemcpyDeviceToHost));
     if (L) VITVS_HIP_CHECK(hipMemcpy(L, h->Lws, P * 7 * 2 * R * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vitvs_timing_enable(vitvs_handle* h, int32_t on) {
+    if (!h) return set_err(h, -1, "null argument");
+    VITVS_HIP_CHECK(hipDeviceSynchronize());
+    h->timing = on != 0;
+    h->ev_used = 0;
+    h->ev_class.clear();
+    return 0;
+}
+
+int vitvs_timing_classes(void) { return KC_COUNT; }
+
+const char* vitvs_timing_class_name(int32_t cls) { return (cls >= 0 && cls < KC_COUNT) ? kClassNames[cls] : ""; }
+
+int vitvs_timing_collect(vitvs_handle* h, int32_t n_classes, double* total_ms, int32_t* launches) {
+    if (!h || !total_ms || !launches || n_classes < KC_COUNT) return set_err(h, -1, "bad argument");
+    VITVS_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < n_classes; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (size_t i = 0; i < h->ev_class.size(); ++i) {
+        float ms = 0.f;
+        VITVS_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+        total_ms[h->ev_class[i]] += ms;
+        launches[h->ev_class[i]] += 1;
+    }
+    h->ev_used = 0;
+    h->ev_class.clear();
     return 0;
 }
 

@@ -1,0 +1,49 @@
+"""Multi-GPU layout of the hot path: independent frame pairs sharded contiguously over ranks, one
+process per GPU, weights replicated, and a single collective per update — the all-gather of the
+6-double twists (48 bytes per pair; latency-bound, so a flat gather, never a ring of buckets).
+
+The reference has no distributed code; this is the 8-camera-rig layout of
+BASELINE.json configs[3].  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code runs
+on "gloo" for the CPU tests (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+
+def shard_range(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) of the pairs rank ``rank`` owns: contiguous, sizes differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError("rank outside the world")
+    base, extra = divmod(n_pairs, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def gather_velocities(v_local: torch.Tensor, n_pairs: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
+    """All ranks receive v_c of every pair, [n_pairs, 6] float64, in global pair order.
+
+    ``v_local`` is this rank's [n_local, 6] block (n_local from ``shard_range``).  Equal shards use
+    one ``all_gather_into_tensor``; ragged shards are padded to the largest shard first."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(n_pairs, r, world) for r in range(world)]
+    n_max = max(e - b for b, e in sizes)
+    b, e = sizes[rank]
+    if v_local.shape != (e - b, 6):
+        raise ValueError(f"rank {rank} should hold {(e - b, 6)}, got {tuple(v_local.shape)}")
+    if all(e2 - b2 == n_max for b2, e2 in sizes):
+        full = out if out is not None else torch.empty((n_pairs, 6), dtype=v_local.dtype, device=v_local.device)
+        dist.all_gather_into_tensor(full, v_local.contiguous(), group=group)
+        return full
+    padded = torch.zeros((n_max, 6), dtype=v_local.dtype, device=v_local.device)
+    padded[: e - b] = v_local
+    buf = torch.empty((world * n_max, 6), dtype=v_local.dtype, device=v_local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    full = out if out is not None else torch.empty((n_pairs, 6), dtype=v_local.dtype, device=v_local.device)
+    for r, (b2, e2) in enumerate(sizes):
+        full[b2:e2] = buf[r * n_max: r * n_max + (e2 - b2)]
+    return full

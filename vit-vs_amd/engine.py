@@ -233,6 +233,18 @@ class Engine:
         sel, cnt = self._selection_args(mode, selection, n, self.tokens)
         return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared)
 
+    # ------------------------------------------------------------------ measurement hooks
+    def timing_enable(self, on: bool = True):
+        self._check(self.lib.vitvs_timing_enable(self.handle, int(on)), "vitvs_timing_enable")
+
+    def timing_collect(self) -> dict:
+        """{kernel class: (total ms between its HIP event pairs, launches)} since the last collect."""
+        n = self.lib.vitvs_timing_classes()
+        ms = (C.c_double * n)()
+        cnt = (C.c_int32 * n)()
+        self._check(self.lib.vitvs_timing_collect(self.handle, n, ms, cnt), "vitvs_timing_collect")
+        return {self.lib.vitvs_timing_class_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
     def last_details(self, n_pairs: int = 1) -> dict:
         """Host copies of what the last servo call left on the device (synchronises)."""
         t, r = getattr(self, "_last_tokens", self.tokens), self.max_rows
