@@ -48,9 +48,10 @@ def kernel_work(cfg, n_img, n_pairs, es, binned):
         "layernorm": (8.0 * m * d, m * d * (4 + es)),
         "qkv": (2.0 * m * 3 * d * d, (m * d + 3 * d * d + m * 3 * d) * es),
         "attention": (4.0 * n_img * n * n * d, (m * 3 * d + m * d) * es),
-        "proj": (2.0 * m * d * d, (m * d + d * d) * es + 2 * m * d * 4),
+        "proj": (2.0 * m * d * d, (m * d + d * d) * es + m * d * 4),
         "fc1": (2.0 * m * h * d, (m * d + h * d + m * h) * es),
-        "fc2": (2.0 * m * d * h, (m * h + d * h) * es + 2 * m * d * 4),
+        "fc2": (2.0 * m * d * h, (m * h + d * h) * es + m * d * 4),
+        "residual_ln": (12.0 * m * d, m * d * (4 + 4 + 4 + es)),
         "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),
         "gram_argmax": (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4),
         "servo": (0.0, n_pairs * t * 16),
@@ -60,7 +61,7 @@ def kernel_work(cfg, n_img, n_pairs, es, binned):
 def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=20.0):
     from oracle import servo_ref as sr
     from oracle import vit_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     frames = np.stack([des, cur])
 
     def update():
@@ -70,11 +71,10 @@ def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=20.0):
                                u_max=params.u_max, v_max=params.v_max, fx=params.f_x, fy=params.f_y,
                                lam=params.lambda_)
     torch.manual_seed(121)
-    for _ in range(2):
-        out = update()
+    out = update()
     times = []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 3):
+    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 2):
         t0 = time.perf_counter()
         out = update()
         times.append(time.perf_counter() - t0)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -60,7 +61,7 @@ struct vitvs_handle {
     float *pe_b = nullptr, *cls = nullptr, *pos = nullptr;
     // activations
     void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
-    float *x = nullptr, *dn = nullptr, *sq = nullptr;
+    float *x = nullptr, *dn = nullptr, *sq = nullptr, *part = nullptr;  // part: split-K partial sums [8][M][D]
     size_t dn_elems = 0;
     unsigned long long *row_best = nullptr, *col_best = nullptr;
     size_t best_elems = 0;
@@ -82,13 +83,17 @@ struct vitvs_handle {
     // captured hipGraphs of compute_velocity_dev, keyed on the argument tuple
     struct GraphEntry {
         std::vector<uintptr_t> key;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
+        hipGraph_t graph[3] = {nullptr, nullptr, nullptr};      // chain A, chain B, tail
+        hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
         uint64_t last_use = 0;
     };
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     bool use_graphs = true;
+    // second launch chain (see forward())
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool two_chains = true;
 };
 
 namespace {
@@ -161,10 +166,11 @@ hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 enum KernelClass : int {
     KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
-    KC_GRAM, KC_SERVO, KC_COUNT
+    KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_COUNT
 };
 const char* const kClassNames[KC_COUNT] = {"patchify", "patch_embed", "layernorm", "qkv", "attention", "proj",
-                                           "fc1", "fc2", "descriptors", "gram_argmax", "servo"};
+                                           "fc1", "fc2", "descriptors", "gram_argmax", "servo",
+                                           "residual_ln"};
 
 // Brackets one launch with a HIP event pair on its stream when timing is enabled.
 struct Span {
@@ -190,37 +196,78 @@ struct Span {
     }
 };
 
-int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uint8_t* cur, hipStream_t st) {
+// Forward of images [i0, i0 + cnt) of the call's image list (desired frames first, then current
+// frames) on stream `st`: an independent chain of launches touching only those images' rows.
+int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part,
+                  hipStream_t st) {
     const vitvs_config& c = h->cfg;
-    const int n_img = n_des + n_cur;
-    if (n_img <= 0 || n_img > h->n_img_max) return set_err(h, -3, "frame count exceeds the handle's capacity");
-    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
-    const int M = n_img * h->N, D = c.dim;
+    const int M = cnt * h->N, D = c.dim;
+    const size_t es = elem_size(h->prec);
+    const size_t img_bytes = (size_t)c.img_size * c.img_size * 3;
+    const size_t row0 = (size_t)i0 * h->N;
+    float* x = h->x + row0 * D;
+    unsigned char* xn = (unsigned char*)h->xn + row0 * D * es;
+    unsigned char* qkv = (unsigned char*)h->qkv + row0 * 3 * D * es;
+    unsigned char* attn = (unsigned char*)h->attn + row0 * D * es;
+    unsigned char* hid = (unsigned char*)h->hid + row0 * h->hidden * es;
+    unsigned char* Ape = (unsigned char*)h->Ape + (size_t)i0 * h->T * h->Kp * es;
     PatchifyArgs pa;
-    pa.des = des; pa.cur = cur; pa.n_des = n_des; pa.n_cur = n_cur;
+    pa.n_des = std::max(0, std::min(i0 + cnt, n_des) - i0);
+    pa.n_cur = cnt - pa.n_des;
+    pa.des = des ? des + (size_t)std::min(i0, n_des) * img_bytes : nullptr;
+    pa.cur = cur ? cur + (size_t)std::max(i0 - n_des, 0) * img_bytes : nullptr;
     pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
     for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
     pa.cls = h->cls; pa.pos = h->pos;
     int rc;
-    { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, h->Ape, h->x, st); }
+    { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, Ape, x, st); }
     if (rc) return set_err(h, rc, "patchify launch failed");
     { Span sp(h, KC_PATCH_EMBED, st);
-      rc = launch_patch_embed(h->prec, h->Ape, h->pe_w, h->pe_b, h->pos, h->x, n_img, h->T, D, h->Kp, st); }
+      rc = launch_patch_embed(h->prec, Ape, h->pe_w, h->pe_b, h->pos, x, cnt, h->T, D, h->Kp, st); }
     if (rc) return set_err(h, rc, "patch-embed launch failed");
+    // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
+    // fc2 (split-K partials) -> [residual + norm1 of block i+1].  Only block 0's norm1 is a launch of its own.
+    { Span sp(h, KC_LAYERNORM, st);
+      rc = launch_layernorm(h->prec, x, h->blk[0].n1w, h->blk[0].n1b, xn, M, D, c.ln_eps, st); }
+    if (rc) return set_err(h, rc, "layernorm launch failed");
+    const int s_proj = splitk_slices(h->prec, M, D, D), s_fc2 = splitk_slices(h->prec, M, D, h->hidden);
     for (int i = 0; i < c.blocks; ++i) {
         const Block& b = h->blk[i];
-        { Span sp(h, KC_LAYERNORM, st); rc = launch_layernorm(h->prec, h->x, b.n1w, b.n1b, h->xn, M, D, c.ln_eps, st); }
-        if (!rc) { Span sp(h, KC_QKV, st); rc = launch_linear(h->prec, h->xn, b.qkvw, b.qkvb, h->qkv, M, 3 * D, D, 0, st); }
-        if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, h->qkv, h->attn, n_img, h->N, c.heads, st); }
-        if (!rc) { Span sp(h, KC_PROJ, st);
-                   rc = launch_linear_residual(h->prec, h->attn, b.projw, b.projb, b.ls1, h->x, M, D, D, st); }
-        if (!rc) { Span sp(h, KC_LAYERNORM, st); rc = launch_layernorm(h->prec, h->x, b.n2w, b.n2b, h->xn, M, D, c.ln_eps, st); }
-        if (!rc) { Span sp(h, KC_FC1, st); rc = launch_linear(h->prec, h->xn, b.fc1w, b.fc1b, h->hid, M, h->hidden, D, 1, st); }
-        if (!rc) { Span sp(h, KC_FC2, st);
-                   rc = launch_linear_residual(h->prec, h->hid, b.fc2w, b.fc2b, b.ls2, h->x, M, D, h->hidden, st); }
+        const Block* nx = (i + 1 < c.blocks) ? &h->blk[i + 1] : nullptr;
+        { Span sp(h, KC_QKV, st); rc = launch_linear(h->prec, xn, b.qkvw, b.qkvb, qkv, M, 3 * D, D, 0, st); }
+        if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, qkv, attn, cnt, h->N, c.heads, st); }
+        if (!rc) { Span sp(h, KC_PROJ, st); rc = launch_linear_partial(h->prec, attn, b.projw, part, M, D, D, s_proj, st); }
+        if (!rc) { Span sp(h, KC_RESIDUAL_LN, st);
+                   rc = launch_residual_ln(h->prec, x, part, s_proj, b.projb, b.ls1, b.n2w, b.n2b, xn, M, D, c.ln_eps, st); }
+        if (!rc) { Span sp(h, KC_FC1, st); rc = launch_linear(h->prec, xn, b.fc1w, b.fc1b, hid, M, h->hidden, D, 1, st); }
+        if (!rc) { Span sp(h, KC_FC2, st); rc = launch_linear_partial(h->prec, hid, b.fc2w, part, M, D, h->hidden, s_fc2, st); }
+        if (!rc) { Span sp(h, KC_RESIDUAL_LN, st);
+                   rc = launch_residual_ln(h->prec, x, part, s_fc2, b.fc2b, b.ls2, nx ? nx->n1w : nullptr,
+                                           nx ? nx->n1b : nullptr, xn, M, D, c.ln_eps, st); }
         if (rc) return set_err(h, rc, "block launch failed");
     }
     return 0;
+}
+
+// The images of one call are independent until the correspondence stage, and at one frame pair each
+// launch fills well under half of the chip, so the image list is cut in two chains that run
+// concurrently: the first half on the caller's stream, the second on the handle's side stream
+// (fork / join with events; inside a stream capture this becomes two parallel branches of the graph).
+int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uint8_t* cur, hipStream_t st) {
+    const int n_img = n_des + n_cur;
+    if (n_img <= 0 || n_img > h->n_img_max) return set_err(h, -3, "frame count exceeds the handle's capacity");
+    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
+    const size_t part_half = (size_t)8 * (h->n_img_max / 2 + 1) * h->N * h->cfg.dim;
+    if (n_img == 1 || !h->two_chains)
+        return forward_chain(h, 0, n_img, n_des, des, cur, h->part, st);
+    const int first = n_img / 2;
+    VITVS_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+    VITVS_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    int rc = forward_chain(h, 0, first, n_des, des, cur, h->part, st);
+    int rc2 = forward_chain(h, first, n_img - first, n_des, des, cur, h->part + part_half, h->side);
+    VITVS_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+    VITVS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+    return rc ? rc : rc2;
 }
 
 int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const double* K, int mode,
@@ -289,6 +336,22 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->blk.resize(cfg->blocks);
     const char* ng = getenv("VITVS_NO_GRAPH");
     h->use_graphs = !(ng && ng[0] == '1');
+    const char* nc = getenv("VITVS_ONE_CHAIN");
+    // Off by default: on this platform kernels of different queues were measured to alternate rather
+    // than overlap (rocprofv3 timeline, profiles/), so the second chain only adds fork/join cost.
+    const char* tc = getenv("VITVS_TWO_CHAINS");
+    (void)nc;
+    h->two_chains = (tc && tc[0] == '1');
+    // A different priority class gives the side stream a hardware queue of its own (streams of one
+    // priority can share a queue, which would serialise the two chains).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return set_err(nullptr, -2, "could not create the side stream / events");
+    }
     const size_t M = (size_t)h->n_img_max * h->N, D = cfg->dim, es = elem_size(h->prec);
     int rc = 0;
     unsigned char* p8 = nullptr;
@@ -301,6 +364,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     ALLOC_BYTES(hid, M * h->hidden * es);
 #undef ALLOC_BYTES
     if (!rc) rc = dev_alloc(h, &h->x, M * D);
+    if (!rc) rc = dev_alloc(h, &h->part, 2 * (size_t)8 * (h->n_img_max / 2 + 1) * h->N * D);
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
@@ -337,11 +401,15 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 
 void vitvs_destroy(vitvs_handle* h) {
     if (!h) return;
-    for (auto& g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    for (auto& g : h->graphs)
+        for (int k = 0; k < 3; ++k) {
+            if (g.exec[k]) (void)hipGraphExecDestroy(g.exec[k]);
+            if (g.graph[k]) (void)hipGraphDestroy(g.graph[k]);
+        }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -474,22 +542,61 @@ int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, con
     return run_servo(h, 1, T, Z_mm, K, select_mode, selection, h->st_nsel, v_c, status, st);
 }
 
-static int compute_velocity_body(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
-                                 int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
-                                 const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
-                                 hipStream_t st) {
-    const int n_des = des_shared ? 1 : n_pairs;
-    int rc = forward(h, n_des, I_des, n_pairs, I_cur, st);
-    if (rc) return rc;
+// The update is three launch segments: forward of the first half of the image list (A, caller's
+// stream), forward of the second half (B, side stream, concurrent with A) and the tail
+// (descriptors, Gram + argmax, control law) after the join.
+struct UpdateArgs {
+    int32_t n_pairs, des_shared, select_mode;
+    const uint8_t *I_cur, *I_des;
+    const uint16_t* Z_mm;
+    const double* K;
+    const int32_t *selection, *n_selected;
+    double* v_c;
+    int32_t* status;
+};
+
+static int segment_forward(vitvs_handle* h, const UpdateArgs& u, int which, hipStream_t st) {
+    const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
+    const int first = h->two_chains ? n_img / 2 : n_img;
+    const size_t part_half = (size_t)8 * (h->n_img_max / 2 + 1) * h->N * h->cfg.dim;
+    if (which == 0) return forward_chain(h, 0, first, n_des, u.I_des, u.I_cur, h->part, st);
+    if (first == n_img) return 0;
+    return forward_chain(h, first, n_img - first, n_des, u.I_des, u.I_cur, h->part + part_half, st);
+}
+
+static int segment_tail(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
+    const int n_des = u.des_shared ? 1 : u.n_pairs;
+    int rc;
     { Span sp(h, KC_DESCRIPTORS, st);
-      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st); }
+      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st); }
     if (rc) return set_err(h, rc, "descriptor launch failed");
-    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)n_pairs * h->T * 8, st));
-    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)n_pairs * h->T * 8, st));
+    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)u.n_pairs * h->T * 8, st));
+    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)u.n_pairs * h->T * 8, st));
     { Span sp(h, KC_GRAM, st);
-      rc = launch_gram_argmax(h->dn, h->T, h->Dp, n_pairs, des_shared ? 1 : 0, h->row_best, h->col_best, st); }
+      rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");
-    return run_servo(h, n_pairs, h->T, Z_mm, K, select_mode, selection, n_selected, v_c, status, st);
+    return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.selection, u.n_selected, u.v_c, u.status, st);
+}
+
+static int capture_segment(vitvs_handle* h, hipStream_t st, hipGraphExec_t* exec, hipGraph_t* graph, int rc_launch_dummy,
+                           const UpdateArgs& u, int which) {
+    (void)rc_launch_dummy;
+    VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = (which < 2) ? segment_forward(h, u, which, st) : segment_tail(h, u, st);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __FILE__, __LINE__);
+    e = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    *graph = g;
+    return 0;
 }
 
 int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
@@ -498,51 +605,70 @@ int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* 
                                void* stream) {
     if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
-    hipStream_t st = as_stream(stream);
-    if (!h->use_graphs || h->timing || st == nullptr)
-        return compute_velocity_body(h, n_pairs, I_cur, I_des, des_shared, Z_mm, K, select_mode, selection, n_selected,
-                                     v_c, status, st);
-    // The whole update is one hipGraph per distinct argument tuple (launch-bound chain of ~90 kernels).
-    std::vector<uintptr_t> key = {(uintptr_t)n_pairs, (uintptr_t)I_cur, (uintptr_t)I_des, (uintptr_t)des_shared,
-                                  (uintptr_t)Z_mm, (uintptr_t)K, (uintptr_t)select_mode, (uintptr_t)selection,
-                                  (uintptr_t)n_selected, (uintptr_t)v_c, (uintptr_t)status};
-    for (auto& g : h->graphs)
-        if (g.key == key) {
-            g.last_use = ++h->graph_clock;
-            h->last_pairs = n_pairs; h->last_T = h->T;
-            VITVS_HIP_CHECK(hipGraphLaunch(g.exec, st));
-            return 0;
-        }
     if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
-    VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = compute_velocity_body(h, n_pairs, I_cur, I_des, des_shared, Z_mm, K, select_mode, selection, n_selected,
-                                   v_c, status, st);
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+    hipStream_t st = as_stream(stream);
+    UpdateArgs u{n_pairs, des_shared, select_mode, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
+    const bool graphs = h->use_graphs && !h->timing && st != nullptr;
+    vitvs_handle::GraphEntry* ge = nullptr;
+    if (graphs) {
+        std::vector<uintptr_t> key = {(uintptr_t)n_pairs, (uintptr_t)I_cur, (uintptr_t)I_des, (uintptr_t)des_shared,
+                                      (uintptr_t)Z_mm, (uintptr_t)K, (uintptr_t)select_mode, (uintptr_t)selection,
+                                      (uintptr_t)n_selected, (uintptr_t)v_c, (uintptr_t)status};
+        for (auto& g : h->graphs)
+            if (g.key == key) ge = &g;
+        if (!ge) {
+            if (h->graphs.size() >= 8) {  // evict the least recently used entry
+                size_t victim = 0;
+                for (size_t i = 1; i < h->graphs.size(); ++i)
+                    if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
+                for (int k = 0; k < 3; ++k) {
+                    if (h->graphs[victim].exec[k]) (void)hipGraphExecDestroy(h->graphs[victim].exec[k]);
+                    if (h->graphs[victim].graph[k]) (void)hipGraphDestroy(h->graphs[victim].graph[k]);
+                }
+                h->graphs.erase(h->graphs.begin() + victim);
+            }
+            vitvs_handle::GraphEntry fresh;
+            fresh.key = key;
+            int rc = capture_segment(h, st, &fresh.exec[0], &fresh.graph[0], 0, u, 0);
+            if (!rc && h->two_chains) rc = capture_segment(h, h->side, &fresh.exec[1], &fresh.graph[1], 0, u, 1);
+            if (!rc) rc = capture_segment(h, st, &fresh.exec[2], &fresh.graph[2], 0, u, 2);
+            if (rc) {
+                for (int k = 0; k < 3; ++k) {
+                    if (fresh.exec[k]) (void)hipGraphExecDestroy(fresh.exec[k]);
+                    if (fresh.graph[k]) (void)hipGraphDestroy(fresh.graph[k]);
+                }
+                return rc;
+            }
+            h->graphs.push_back(fresh);
+            ge = &h->graphs.back();
+        }
+        ge->last_use = ++h->graph_clock;
     }
-    if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __FILE__, __LINE__);
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(graph);
-        return fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    // fork: the side stream starts after everything already queued on the caller's stream
+    const bool fork = h->two_chains;
+    if (fork) {
+        VITVS_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+        VITVS_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
-    if (h->graphs.size() >= 8) {  // evict the least recently used entry
-        size_t victim = 0;
-        for (size_t i = 1; i < h->graphs.size(); ++i)
-            if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
-        (void)hipGraphExecDestroy(h->graphs[victim].exec);
-        (void)hipGraphDestroy(h->graphs[victim].graph);
-        h->graphs.erase(h->graphs.begin() + victim);
+    int rc = 0;
+    if (ge) {
+        VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[0], st));
+        if (fork) VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[1], h->side));
+    } else {
+        rc = segment_forward(h, u, 0, st);
+        if (!rc && fork) rc = segment_forward(h, u, 1, h->side);
     }
-    vitvs_handle::GraphEntry ge;
-    ge.key = key; ge.graph = graph; ge.exec = exec; ge.last_use = ++h->graph_clock;
-    h->graphs.push_back(ge);
-    VITVS_HIP_CHECK(hipGraphLaunch(exec, st));
-    return 0;
+    if (fork) {
+        VITVS_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+        VITVS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    if (rc) return rc;
+    if (ge) {
+        h->last_pairs = n_pairs; h->last_T = h->T;
+        VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[2], st));
+        return 0;
+    }
+    return segment_tail(h, u, st);
 }
 
 int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,

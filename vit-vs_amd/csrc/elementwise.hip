@@ -119,6 +119,116 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
     return launch_ln_t<bf16>(x, gamma, beta, (bf16*)out, M, D, eps, stream);
 }
 
+// ------------------------------------------------------------------------------------ residual + LayerNorm
+// Finishes a split-K linear layer: x += ls * (sum_z part[z] + bias), slices summed in index order,
+// then (optionally) the next LayerNorm of the freshly updated row — one pass, one wave per row.
+// Reference: dino_patch/block.py:90-96,112-115 (x + ls(f(norm(x)))), followed by the next norm.
+constexpr int SMAX = 8;  // most K slices splitk_slices() ever picks
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void residual_ln_kernel(float* __restrict__ x, const float* __restrict__ part,
+                                                          int splits, const float* __restrict__ bias,
+                                                          const float* __restrict__ ls, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ out, int M,
+                                                          float eps) {
+    constexpr int D = 128 * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float2* xr = reinterpret_cast<float2*>(x + (size_t)row * D);
+    const float2* b2 = reinterpret_cast<const float2*>(bias);
+    const float2* l2 = reinterpret_cast<const float2*>(ls);
+    // All loads of the row (x and every K slice) are issued before the first add, so the pass costs one
+    // memory latency, not one per slice; the slices are still summed in index order (deterministic).
+    float2 v[NV], pv[SMAX][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+#pragma unroll
+    for (int z = 0; z < SMAX; ++z)
+        if (z < splits) {
+            const float2* pz = reinterpret_cast<const float2*>(part + ((size_t)z * M + row) * D);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) pv[z][i] = pz[i * 64 + lane];
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        float2 acc = pv[0][i];
+#pragma unroll
+        for (int z = 1; z < SMAX; ++z)
+            if (z < splits) {
+                acc.x += pv[z][i].x;
+                acc.y += pv[z][i].y;
+            }
+        const float2 b = b2[c];
+        acc.x += b.x;
+        acc.y += b.y;
+        if (ls) {
+            const float2 g = l2[c];
+            acc.x *= g.x;
+            acc.y *= g.y;
+        }
+        float2 r = v[i];
+        r.x += acc.x;
+        r.y += acc.y;
+        xr[c] = r;
+        v[i] = r;
+        s += r.x + r.y;
+    }
+    if (!gamma) return;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean;
+        q += a * a + b * b;
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float2* g2 = reinterpret_cast<const float2*>(gamma);
+    const float2* be2 = reinterpret_cast<const float2*>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float2 g = g2[i * 64 + lane], b = be2[i * 64 + lane];
+        const float y0 = (v[i].x - mean) * rstd * g.x + b.x;
+        const float y1 = (v[i].y - mean) * rstd * g.y + b.y;
+        T* dst = out + (size_t)row * D + 2 * (i * 64 + lane);
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+        } else {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 h = {(bf16)y0, (bf16)y1};
+            *reinterpret_cast<bf16x2*>(dst) = h;
+        }
+    }
+}
+
+template <typename T>
+static int launch_rln_t(float* x, const float* part, int splits, const float* bias, const float* ls, const float* g,
+                        const float* b, T* out, int M, int D, float eps, hipStream_t stream) {
+    dim3 grid((M + 3) / 4), block(256);
+#define VITVS_RLN(NV) \
+    hipLaunchKernelGGL((residual_ln_kernel<T, NV>), grid, block, 0, stream, x, part, splits, bias, ls, g, b, out, M, eps)
+    switch (D) {
+        case 128: VITVS_RLN(1); break;
+        case 256: VITVS_RLN(2); break;
+        case 384: VITVS_RLN(3); break;
+        case 768: VITVS_RLN(6); break;
+        case 1024: VITVS_RLN(8); break;
+        default: return -2;
+    }
+#undef VITVS_RLN
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_residual_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
+                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream) {
+    if (M <= 0 || splits < 1 || splits > SMAX) return -2;
+    if (p == PREC_F32) return launch_rln_t<float>(x, part, splits, bias, ls, gamma, beta, (float*)out, M, D, eps, stream);
+    return launch_rln_t<bf16>(x, part, splits, bias, ls, gamma, beta, (bf16*)out, M, D, eps, stream);
+}
+
 // ------------------------------------------------------------------------------------ descriptors
 // plain: one wave per patch token: dn = x / max(||x||, 1e-8)
 __global__ __launch_bounds__(256) void desc_plain_kernel(const float* __restrict__ x, float* __restrict__ dn,

@@ -73,6 +73,17 @@ struct EpiPatch {
     }
 };
 
+// Raw fp32 partial sums of one K slice (split-K): part[z][m][n]; bias / LayerScale / residual /
+// LayerNorm are applied by residual_ln_kernel (elementwise.hip), which sums the slices in a fixed
+// order, so the result does not depend on scheduling (no atomics).
+struct EpiPartial {
+    float* part;
+    int M, N;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+        *reinterpret_cast<float4*>(part + ((size_t)blockIdx.z * M + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
 template <typename T, int BM, int BN, class Epi>
 __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, int M, int N,
                                                      int K, Epi epi) {
@@ -80,7 +91,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ A, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
-    gemm_mainloop<T, BM, BN>(A, W, K, K, M, N, m0, n0, 0, K, smem, acc);
+    const int kslice = K / gridDim.z;
+    gemm_mainloop_dma<T, BM, BN>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
 #pragma unroll
@@ -100,16 +112,24 @@ static bool shapes_ok(Precision p, int M, int N, int K) {
 }
 
 template <typename T, class Epi>
-static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream) {
+static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                        int splits = 1) {
     const int mt = (M + 63) / 64;
     // Wide tiles halve the re-reads of A; use them only when they still fill the chip.
-    if ((N % 128) == 0 && (long)mt * (N / 128) >= 224) {
+    if (splits == 1 && (N % 128) == 0 && (long)mt * (N / 128) >= 224) {
         dim3 grid(N / 128, mt);
-        constexpr int lds = GemmTile<64, 128>::LDS_BYTES;
+        constexpr int lds = DmaTile<64, 128>::LDS_BYTES;
+        static bool raised = false;  // 96 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, 64, 128, Epi>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return -1;
+            raised = true;
+        }
         linear_kernel<T, 64, 128, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
     } else {
-        dim3 grid(N / 64, mt);
-        constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
+        dim3 grid(N / 64, mt, splits);
+        constexpr int lds = DmaTile<64, 64>::LDS_BYTES;
         linear_kernel<T, 64, 64, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -132,6 +152,29 @@ int launch_linear_residual(Precision p, const void* A, const void* W, const floa
     EpiResidual e{x, bias, ls, N};
     if (p == PREC_F32) return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream);
     return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+}
+
+int splitk_slices(Precision p, int M, int N, int K) {
+    // Fewest K slices that put a workgroup on every CU, each slice at least 4 k-tiles long;
+    // if none does, the most slices that are still valid.
+    const int bk = (p == PREC_F32) ? 32 : 64;
+    const long tiles = (long)((M + 63) / 64) * (N / 64);
+    int best = 1;
+    for (int c : {1, 2, 3, 4, 6, 8}) {
+        if ((K % (c * bk)) != 0 || K / c < 4 * bk) continue;
+        best = c;
+        if (tiles * c >= 256) break;
+    }
+    return best;
+}
+
+int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
+                          hipStream_t stream) {
+    const int bk = (p == PREC_F32) ? 32 : 64;
+    if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * bk)) != 0) return -2;
+    EpiPartial e{part, M, N};
+    if (p == PREC_F32) return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
+    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,

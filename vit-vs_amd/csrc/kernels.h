@@ -25,6 +25,11 @@ int launch_linear(Precision p, const void* A, const void* W, const float* bias, 
 // x[m][n] += ls[n] * (sum_k A[m][k] W[n][k] + bias[n]); x fp32 residual stream, ls may be null.
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
                            int M, int N, int K, hipStream_t stream);
+// Split-K form for the narrow (N = D) layers: part[z][m][n] = sum over K slice z of A[m][k] W[n][k], fp32,
+// z < splits (splitk_slices picks the count); finished by launch_residual_ln.
+int splitk_slices(Precision p, int M, int N, int K);
+int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
+                          hipStream_t stream);
 // x[img*(T+1) + 1 + t][n] = sum_k Ape[img*T + t][k] Wpe[n][k] + bias[n] + pos[1 + t][n]
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
                        int n_img, int T, int D, int Kp, hipStream_t stream);
@@ -45,6 +50,10 @@ int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hip
 // out[m][:] = LayerNorm(x[m][:]) * gamma + beta, out in precision p.
 int launch_layernorm(Precision p, const float* x, const float* gamma, const float* beta, void* out, int M, int D,
                      float eps, hipStream_t stream);
+// x[m][:] += ls * (sum_z part[z][m][:] + bias)  (fixed slice order), then, if gamma != null,
+// out[m][:] = LayerNorm(x[m][:]) * gamma + beta in precision p.  One pass over the row.
+int launch_residual_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
+                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream);
 // Descriptors for the correspondence stage, fp32, L2-normalised with max(|x|,1e-8):
 //   plain : dn[img][t][D]   = x[img][1+t][:] / max(norm, eps)
 //   binned: dn[img][t][9D]  = 3x3 replicate-clamped neighbourhood concat, then normalised.

@@ -194,15 +194,83 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
         }
     }
 
-    // 5. v_c = -lambda * pinv(L) e by one-sided Jacobi SVD (fp64), wave 0 only
-    if (wave != 0) return;
-    double vout[6] = {0, 0, 0, 0, 0, 0};
-    int sweeps = 0;
+    // 5. v_c = -lambda * pinv(L) e, fp64.
+    // Fast path (L_e of full column rank and well conditioned, the normal servo case): pinv(L) e is the
+    // least-squares solution, obtained from the 6x6 normal equations by Cholesky; 27 threads form
+    // G = L^T L and g = L^T e, one thread factors and solves.  If a pivot falls below 1e-8 of its
+    // diagonal (cond(L) > ~1e4, or rank deficiency, e.g. all-identical zero-padded rows) the general
+    // path below runs instead: one-sided Jacobi SVD with numpy.linalg.pinv's rcond = 1e-15 cut-off.
     int status = ST_OK;
     if (!depth) status = ST_NO_DEPTH;
     else if (none) status = ST_NO_CORRESPONDENCE;
     else if (too_few) status = ST_TOO_FEW;
-    if (status == ST_OK && R > 0) {
+    double* Gs = Llds + 7 * kLdsRows;   // [27] G (21, upper triangle row-major) + g (6); [27..33] solution, [34] flag
+    bool solved = false;
+    if (status == ST_OK && R > 0 && use_lds) {
+        if (tid < 27) {
+            int ca, cb;
+            if (tid < 21) {
+                int q = tid;
+                ca = 0;
+                while (q >= 6 - ca) { q -= 6 - ca; ++ca; }
+                cb = ca + q;
+            } else {
+                ca = tid - 21;
+                cb = 6;
+            }
+            double acc = 0.0;
+            for (int r = 0; r < R; ++r) acc += Lc[ca * rcap + r] * Lc[cb * rcap + r];
+            Gs[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double Gm[6][6], rhs[6];
+            int q = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j) { Gm[i][j] = Gs[q]; Gm[j][i] = Gs[q]; ++q; }
+            for (int i = 0; i < 6; ++i) rhs[i] = Gs[21 + i];
+            bool good = true;
+            double Lf[6][6];
+            for (int j = 0; j < 6 && good; ++j) {
+                double d = Gm[j][j];
+                for (int k = 0; k < j; ++k) d -= Lf[j][k] * Lf[j][k];
+                if (!(d > 1e-8 * Gm[j][j]) || !(Gm[j][j] > 0.0)) { good = false; break; }
+                const double dj = sqrt(d);
+                Lf[j][j] = dj;
+                for (int i = j + 1; i < 6; ++i) {
+                    double t = Gm[i][j];
+                    for (int k = 0; k < j; ++k) t -= Lf[i][k] * Lf[j][k];
+                    Lf[i][j] = t / dj;
+                }
+            }
+            if (good) {
+                double y[6], xsol[6];
+                for (int i = 0; i < 6; ++i) {
+                    double t = rhs[i];
+                    for (int k = 0; k < i; ++k) t -= Lf[i][k] * y[k];
+                    y[i] = t / Lf[i][i];
+                }
+                for (int i = 5; i >= 0; --i) {
+                    double t = y[i];
+                    for (int k = i + 1; k < 6; ++k) t -= Lf[k][i] * xsol[k];
+                    xsol[i] = t / Lf[i][i];
+                }
+                for (int i = 0; i < 6; ++i) Gs[27 + i] = -a.lambda * xsol[i];
+            }
+            Gs[34] = good ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        solved = Gs[34] != 0.0;
+    }
+    if (wave != 0) return;
+    double vout[6] = {0, 0, 0, 0, 0, 0};
+    int sweeps = 0;
+    if (solved) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vout[i] = Gs[27 + i];
+        sweeps = -1;
+    }
+    if (status == ST_OK && R > 0 && !solved) {
         double V[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -280,7 +348,7 @@ int launch_servo(const ServoArgs& a, hipStream_t stream) {
     if (a.n_pairs <= 0 || a.T <= 0 || a.grid * a.grid != a.T || a.max_rows < a.num_pairs || a.num_pairs <= 0) return -2;
     if (a.mode == SEL_DENSE && a.max_rows < a.T) return -2;
     size_t ints = (size_t)3 * a.T + a.max_rows + 8 + 256 + 4;
-    size_t lds = ((ints * 4 + 15) & ~(size_t)15) + (size_t)7 * kLdsRows * 8;
+    size_t lds = ((ints * 4 + 15) & ~(size_t)15) + (size_t)7 * kLdsRows * 8 + 40 * 8;
     if (lds > 64 * 1024) return -3;
     hipLaunchKernelGGL(servo_kernel, dim3(a.n_pairs), dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
