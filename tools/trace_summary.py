@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 kernel-trace CSV by (kernel, grid, block): calls, avg/min duration, share."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"vitvs::", "", name)
+    m = re.match(r"_ZN5vitvs\d+(\w+?)I", name)
+    if m:
+        epi = re.search(r"(EpiStore|EpiPartial|EpiPatch|EpiResidual)", name)
+        kind = "bf16" if "DF16b" in name else "f32"
+        dims = re.search(r"Li(\d+)ELi(\d+)ELi(\d+)E", name)
+        extra = f"<{kind},{'x'.join(dims.groups())}>" if dims else f"<{kind}>"
+        return m.group(1) + extra + (":" + epi.group(1) if epi else "")
+    return name.split("(")[0][:40]
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof/*/*_kernel_trace.csv"))[-1]
+    rows = list(csv.DictReader(open(path)))
+    groups = collections.defaultdict(list)
+    for r in rows:
+        key = (short(r["Kernel_Name"]), f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]}', r["Workgroup_Size_X"])
+        groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    total = sum(sum(v) for v in groups.values())
+    print(f"{'kernel':58s} {'grid':>16s} {'wg':>4s} {'calls':>6s} {'avg_us':>8s} {'min_us':>8s} {'share':>6s}")
+    for key, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{key[0]:58s} {key[1]:>16s} {key[2]:>4s} {len(v):6d} {sum(v) / len(v):8.2f} {min(v):8.2f} {100 * sum(v) / total:5.1f}%")
+
+
+if __name__ == "__main__":
+    main()

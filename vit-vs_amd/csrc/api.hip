@@ -506,7 +506,7 @@ int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);
     if (rc) return rc;
-    rc = launch_descriptors(h->x, h->dn, desc, h->sq, n_frames, h->T, h->grid, h->cfg.dim, h->cfg.binned, st);
+    rc = launch_descriptors(h->x, h->dn, desc, h->sq, n_frames, h->T, h->grid, h->cfg.dim, h->cfg.binned, nullptr, nullptr, 0, st);
     if (rc) return set_err(h, rc, "descriptor launch failed");
     return 0;
 }
@@ -568,10 +568,9 @@ static int segment_tail(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs;
     int rc;
     { Span sp(h, KC_DESCRIPTORS, st);
-      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned, st); }
+      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned,
+                              h->row_best, h->col_best, u.n_pairs * h->T, st); }
     if (rc) return set_err(h, rc, "descriptor launch failed");
-    VITVS_HIP_CHECK(hipMemsetAsync(h->row_best, 0, (size_t)u.n_pairs * h->T * 8, st));
-    VITVS_HIP_CHECK(hipMemsetAsync(h->col_best, 0, (size_t)u.n_pairs * h->T * 8, st));
     { Span sp(h, KC_GRAM, st);
       rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");

@@ -12,11 +12,11 @@
 
 namespace vitvs {
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gram_argmax_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
+template <int BM, int BN, int KG>
+__global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
                                                           int des_shared, unsigned long long* __restrict__ row_best,
                                                           unsigned long long* __restrict__ col_best) {
-    using Tile = GemmTile<BM, BN>;
+    using Tile = GemmTile<BM, BN, KG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     const int n_des = des_shared ? 1 : n_pairs;
@@ -24,9 +24,17 @@ __global__ __launch_bounds__(256) void gram_argmax_kernel(const float* __restric
     const float* d2 = dn + (size_t)(n_des + b) * T * Dp;            // current frame tokens (cols j)
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
-    gemm_mainloop<float, BM, BN>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    gemm_mainloop<float, BM, BN, KG>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    // with two k-groups each group holds full sums only for the column tiles it owns; mask the rest
+    const int kg = (KG == 2) ? k_group() : 0;
+#pragma unroll
+    for (int ni = 0; ni < Tile::NT; ++ni)
+        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) {
+#pragma unroll
+            for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;
     unsigned long long* rb = row_best + (size_t)b * T;
     unsigned long long* cb = col_best + (size_t)b * T;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void gram_argmax_kernel(const float* __restric
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gram_dense_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
                                                          int des_shared, float* __restrict__ S) {
-    using Tile = GemmTile<BM, BN>;
+    using Tile = GemmTile<BM, BN, 1>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     const int n_des = des_shared ? 1 : n_pairs;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void gram_dense_kernel(const float* __restrict
     const float* d2 = dn + (size_t)(n_des + b) * T * Dp;
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
-    gemm_mainloop<float, BM, BN>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    gemm_mainloop<float, BM, BN, 1>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     float* out = S + (size_t)b * T * T;
@@ -136,15 +144,23 @@ int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shar
                        unsigned long long* col_best, hipStream_t stream) {
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
     dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
-    constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
-    gram_argmax_kernel<64, 64><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, row_best, col_best);
+    if (T <= 512 && (Dp / 32) % 2 == 0) {
+        // few tokens: 32x32 tiles (49 workgroups at T = 196 instead of 16) with two k-groups
+        using Tile = GemmTile<32, 32, 2>;
+        dim3 g32((T + 31) / 32, (T + 31) / 32, n_pairs);
+        gram_argmax_kernel<32, 32, 2><<<g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream>>>(dn, T, Dp, n_pairs, des_shared,
+                                                                                       row_best, col_best);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
+    gram_argmax_kernel<64, 64, 1><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, row_best, col_best);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream) {
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
     dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
-    constexpr int lds = GemmTile<64, 64>::LDS_BYTES;
+    constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
     gram_dense_kernel<64, 64><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, S);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <typename T>
 static int launch_ln_t(const float* x, const float* g, const float* b, T* out, int M, int D, float eps,
                        hipStream_t stream) {
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
     switch (D) {
         case 384: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, stream, x, g, b, out, M, eps); break;
         case 768: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, stream, x, g, b, out, M, eps); break;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void residual_ln_kernel(float* __restrict__ x,
 template <typename T>
 static int launch_rln_t(float* x, const float* part, int splits, const float* bias, const float* ls, const float* g,
                         const float* b, T* out, int M, int D, float eps, hipStream_t stream) {
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
 #define VITVS_RLN(NV) \
     hipLaunchKernelGGL((residual_ln_kernel<T, NV>), grid, block, 0, stream, x, part, splits, bias, ls, g, b, out, M, eps)
     switch (D) {
@@ -232,9 +232,15 @@ int launch_residual_ln(Precision p, float* x, const float* part, int splits, con
 // ------------------------------------------------------------------------------------ descriptors
 // plain: one wave per patch token: dn = x / max(||x||, 1e-8)
 __global__ __launch_bounds__(256) void desc_plain_kernel(const float* __restrict__ x, float* __restrict__ dn,
-                                                         float* __restrict__ raw, int n_img, int T, int D) {
+                                                         float* __restrict__ raw, int n_img, int T, int D,
+                                                         unsigned long long* zero_a, unsigned long long* zero_b,
+                                                         int zero_count) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    {   // clears the packed (similarity, index) keys the Gram kernel will atomicMax into
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        if (gid < zero_count) { zero_a[gid] = 0ull; zero_b[gid] = 0ull; }
+    }
     if (tok >= n_img * T) return;
     const int img = tok / T, t = tok - img * T;
     const float* src = x + ((size_t)img * (T + 1) + 1 + t) * D;
@@ -253,9 +259,14 @@ __global__ __launch_bounds__(256) void desc_plain_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void token_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ sq,
-                                                           int n_img, int T, int D) {
+                                                           int n_img, int T, int D, unsigned long long* zero_a,
+                                                           unsigned long long* zero_b, int zero_count) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    {
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        if (gid < zero_count) { zero_a[gid] = 0ull; zero_b[gid] = 0ull; }
+    }
     if (tok >= n_img * T) return;
     const int img = tok / T, t = tok - img * T;
     const float* src = x + ((size_t)img * (T + 1) + 1 + t) * D;
@@ -314,13 +325,16 @@ int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStr
 }
 
 int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
-                       int binned, hipStream_t stream) {
+                       int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
+                       hipStream_t stream) {
     const int toks = n_img * T;
-    if (toks <= 0 || grid * grid != T) return -2;
+    if (toks <= 0 || grid * grid != T || zero_count > toks * 64) return -2;
     if (!binned) {
-        hipLaunchKernelGGL(desc_plain_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, dn, raw, n_img, T, D);
+        hipLaunchKernelGGL(desc_plain_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, dn, raw, n_img, T, D,
+                           zero_a, zero_b, zero_count);
     } else {
-        hipLaunchKernelGGL(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sqnorm_ws, n_img, T, D);
+        hipLaunchKernelGGL(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sqnorm_ws, n_img, T, D,
+                           zero_a, zero_b, zero_count);
         hipLaunchKernelGGL(desc_binned_kernel, dim3(toks), dim3(256), 0, stream, x, sqnorm_ws, dn, raw, n_img, T, grid,
                            D);
     }

@@ -22,6 +22,15 @@ __device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
 }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26): two orders below bf16 output rounding, a
+// fraction of libm erff's instruction count.  Used only when the layer's output is bf16.
+__device__ __forceinline__ float gelu_erf_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-x * x);
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
 
 template <typename T>
 struct EpiStore {
@@ -34,7 +43,7 @@ struct EpiStore {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+            for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
         store4<T>(out + (size_t)m * ldo + n, v);
     }
@@ -84,19 +93,21 @@ struct EpiPartial {
     }
 };
 
-template <typename T, int BM, int BN, class Epi>
-__global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, int M, int N,
-                                                     int K, Epi epi) {
-    using Tile = GemmTile<BM, BN>;
+template <typename T, int BM, int BN, int KG, class Epi>
+__global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, int M,
+                                                          int N, int K, Epi epi) {
+    using Tile = GemmTile<BM, BN, KG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
     const int kslice = K / gridDim.z;
-    gemm_mainloop_dma<T, BM, BN>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;
+    const int kg = (KG == 2) ? k_group() : 0;
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
+        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
         const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
@@ -106,33 +117,77 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ A, co
     }
 }
 
+static int k_tile(Precision p) { return (p == PREC_F32) ? 32 : 64; }
+
 static bool shapes_ok(Precision p, int M, int N, int K) {
-    const int bk = (p == PREC_F32) ? 32 : 64;
-    return M > 0 && N > 0 && K > 0 && (K % bk) == 0 && (N % 64) == 0;
+    return M > 0 && N > 0 && K > 0 && (K % k_tile(p)) == 0 && (N % 64) == 0;
+}
+
+// Tile plan.  In the one-frame-pair regime a launch cannot fill the chip, and a second wave of
+// workgroups costs more than bigger tiles save (measured: 336 workgroups of 64x64 ran 2.4 us longer than
+// 252), so: the column-tile width with the MOST workgroups that still fit the 256 CUs; if even the
+// widest tile needs more than 256 workgroups the problem is large and the widest tile wins.  Two
+// k-groups (8 waves, intra-workgroup split-K) whenever one workgroup per CU is all there is.
+struct TilePlan {
+    int bn, kg;
+};
+static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixed64) {
+    const long mt = (M + 63) / 64;
+    int bn = 64;
+    if (!fixed64) {
+        long best = -1;
+        for (int c : {128, 96, 64}) {
+            if (N % c) continue;
+            const long wgs = mt * (N / c);
+            if (wgs <= 256 && wgs > best) { best = wgs; bn = c; }
+        }
+        if (best < 0) bn = (N % 128 == 0) ? 128 : 64;
+    }
+    const long wgs = mt * (N / bn) * splits;
+    const int kg = (wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
+    return TilePlan{bn, kg};
+}
+
+template <typename T, int BN, int KG, class Epi>
+static int launch_one(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream, int splits) {
+    using Tile = GemmTile<64, BN, KG>;
+    static bool raised = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, 64, BN, KG, Epi>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES) != hipSuccess)
+            return -1;
+        raised = true;
+    }
+    dim3 grid(N / BN, (M + 63) / 64, splits);
+    linear_kernel<T, 64, BN, KG, Epi><<<grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream>>>(A, W, M, N, K, epi);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <typename T, class Epi>
 static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                        int splits = 1) {
-    const int mt = (M + 63) / 64;
-    // Wide tiles halve the re-reads of A; use them only when they still fill the chip.
-    if (splits == 1 && (N % 128) == 0 && (long)mt * (N / 128) >= 224) {
-        dim3 grid(N / 128, mt);
-        constexpr int lds = DmaTile<64, 128>::LDS_BYTES;
-        static bool raised = false;  // 96 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, 64, 128, Epi>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                return -1;
-            raised = true;
-        }
-        linear_kernel<T, 64, 128, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
-    } else {
-        dim3 grid(N / 64, mt, splits);
-        constexpr int lds = DmaTile<64, 64>::LDS_BYTES;
-        linear_kernel<T, 64, 64, Epi><<<grid, dim3(256), lds, stream>>>(A, W, M, N, K, epi);
+                        int splits = 1, bool fixed64 = false) {
+    const int bk = 128 / (int)sizeof(T);
+    const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
+    if (pl.bn == 128) {
+        if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+        return launch_one<T, 128, 1, Epi>(A, W, M, N, K, epi, stream, splits);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (pl.bn == 96) {
+        if (pl.kg == 2) return launch_one<T, 96, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+        return launch_one<T, 96, 1, Epi>(A, W, M, N, K, epi, stream, splits);
+    }
+    if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+    return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);
+}
+
+// narrow layers / patch embed: 64-wide tiles only (keeps the number of instantiations down)
+template <typename T, class Epi>
+static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                          int splits = 1) {
+    const int bk = 128 / (int)sizeof(T);
+    const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, true);
+    if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+    return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);
 }
 
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
@@ -150,31 +205,29 @@ int launch_linear_residual(Precision p, const void* A, const void* W, const floa
                            int M, int N, int K, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;
     EpiResidual e{x, bias, ls, N};
-    if (p == PREC_F32) return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream);
-    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+    if (p == PREC_F32) return launch_tiles64<float>((const float*)A, (const float*)W, M, N, K, e, stream);
+    return launch_tiles64<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
 int splitk_slices(Precision p, int M, int N, int K) {
-    // Fewest K slices that put a workgroup on every CU, each slice at least 4 k-tiles long;
-    // if none does, the most slices that are still valid.
-    const int bk = (p == PREC_F32) ? 32 : 64;
+    // The most K slices that still put at most one workgroup on every CU (each slice >= 4 k-tiles);
+    // none if the tiles alone already cover the chip.
+    const int bk = k_tile(p);
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     int best = 1;
-    for (int c : {1, 2, 3, 4, 6, 8}) {
+    for (int c : {2, 3, 4, 6, 8}) {
         if ((K % (c * bk)) != 0 || K / c < 4 * bk) continue;
-        best = c;
-        if (tiles * c >= 256) break;
+        if (tiles * c <= 256) best = c;
     }
     return best;
 }
 
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
                           hipStream_t stream) {
-    const int bk = (p == PREC_F32) ? 32 : 64;
-    if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * bk)) != 0) return -2;
+    if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
     EpiPartial e{part, M, N};
-    if (p == PREC_F32) return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
-    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
+    if (p == PREC_F32) return launch_tiles64<float>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
+    return launch_tiles64<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
@@ -182,8 +235,8 @@ int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const floa
     const int M = n_img * T;
     if (!shapes_ok(p, M, D, Kp)) return -2;
     EpiPatch e{x, bias, pos, T, D};
-    if (p == PREC_F32) return launch_tiles<float>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
-    return launch_tiles<bf16>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
+    if (p == PREC_F32) return launch_tiles64<float>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
+    return launch_tiles64<bf16>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
 }
 
 }  // namespace vitvs

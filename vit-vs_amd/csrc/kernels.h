@@ -58,8 +58,11 @@ int launch_residual_ln(Precision p, float* x, const float* part, int splits, con
 //   plain : dn[img][t][D]   = x[img][1+t][:] / max(norm, eps)
 //   binned: dn[img][t][9D]  = 3x3 replicate-clamped neighbourhood concat, then normalised.
 // raw (optional, may be null): the un-normalised descriptor in the same layout.
+// zero_a / zero_b (may be null with zero_count 0): zero_count 64-bit words of each are cleared by the
+// same launch (the Gram kernel's atomicMax targets), saving two memset nodes per update.
 int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
-                       int binned, hipStream_t stream);
+                       int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
+                       hipStream_t stream);
 
 // dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);
