@@ -36,10 +36,23 @@ PEAK_MFMA = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
 
+def split_k(m, n, k, bk):
+    """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip."""
+    tiles = -(-m // 64) * (n // 64)
+    best = 1
+    for c in (2, 3, 4, 6, 8):
+        if k % (c * bk) == 0 and k // c >= 4 * bk and tiles * c <= 256:
+            best = c
+    return best
+
+
 def kernel_work(cfg, n_img, n_pairs, es, binned):
     """Algorithmic FLOPs and minimum HBM bytes per LAUNCH of each kernel class."""
     n, t, d, h = cfg.seq, cfg.tokens, cfg.dim, cfg.hidden
     m = n_img * n
+    bk = 128 // es
+    s_proj, s_fc2 = split_k(m, d, d, bk), split_k(m, d, h, bk)
+    s_avg = (s_proj + s_fc2) / 2
     dp = d * (9 if binned else 1)
     kp = -(-cfg.patch_k // 64) * 64
     return {
@@ -48,10 +61,10 @@ def kernel_work(cfg, n_img, n_pairs, es, binned):
         "layernorm": (8.0 * m * d, m * d * (4 + es)),
         "qkv": (2.0 * m * 3 * d * d, (m * d + 3 * d * d + m * 3 * d) * es),
         "attention": (4.0 * n_img * n * n * d, (m * 3 * d + m * d) * es),
-        "proj": (2.0 * m * d * d, (m * d + d * d) * es + m * d * 4),
+        "proj": (2.0 * m * d * d, (m * d + d * d) * es + s_proj * m * d * 4),
         "fc1": (2.0 * m * h * d, (m * d + h * d + m * h) * es),
-        "fc2": (2.0 * m * d * h, (m * h + d * h) * es + m * d * 4),
-        "residual_ln": (12.0 * m * d, m * d * (4 + 4 + 4 + es)),
+        "fc2": (2.0 * m * d * h, (m * h + d * h) * es + s_fc2 * m * d * 4),
+        "residual_ln": (12.0 * m * d, m * d * (4 + 4 * s_avg + 4 + es)),
         "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),
         "gram_argmax": (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4),
         "servo": (0.0, n_pairs * t * 16),
@@ -186,28 +199,52 @@ def main():
     value = updates / elapsed
     es = 2 if args.precision == "bf16" else 4
     work = kernel_work(cfg, 2 * B, B, es, binned)
+    # every timed launch carries the cost of its own event pair; the empty "null_span" measures it
+    null_ms, null_cnt = prof.pop("null_span", (0.0, 0))
+    overhead_s = (null_ms / null_cnt * 1e-3) if null_cnt else 0.0
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
             continue
-        avg = ms / cnt * 1e-3
+        avg = max(ms / cnt * 1e-3 - overhead_s, 1e-7)
         fl, by = work[name]
         kernels[name] = dict(launches_per_step=cnt / n_prof, avg_us=round(avg * 1e6, 3),
-                             step_share_us=round(ms / n_prof * 1e3, 2),
+                             step_share_us=round(avg * cnt / n_prof * 1e6, 2),
                              tflops=round(fl / avg / 1e12, 3), gbps=round(by / avg / 1e9, 1))
-    dom = max(kernels, key=lambda k: kernels[k]["step_share_us"])
-    fl, by = work[dom]
-    avg_s = kernels[dom]["avg_us"] * 1e-6
-    mfma_bound = dom in ("qkv", "proj", "fc1", "fc2", "attention", "patch_embed", "gram_argmax")
+    # roofline object: the kernel SYMBOL with the largest share of the step (proj and fc2 are the same
+    # split-K kernel, as rocprofv3 --stats reports them), priced with its algorithmic work per launch
+    prec_tag = "bf16" if args.precision == "bf16" else "f32"
+    groups = {"linear_partial(proj+fc2)": ["proj", "fc2"]}
+    for k in kernels:
+        if k not in ("proj", "fc2"):
+            groups[k] = [k]
+    def g_share(g): return sum(kernels[c]["step_share_us"] for c in groups[g] if c in kernels)
+    dom = max(groups, key=g_share)
+    members = [c for c in groups[dom] if c in kernels]
+    launches = sum(kernels[c]["launches_per_step"] for c in members)
+    avg_s = g_share(dom) / launches * 1e-6
+    fl = sum(work[c][0] * kernels[c]["launches_per_step"] for c in members) / launches
+    by = sum(work[c][1] * kernels[c]["launches_per_step"] for c in members) / launches
+    symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},64,64,2>:EpiPartial",
+              "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
+              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": f"attention_{'bf16' if prec_tag == 'bf16' else 'f32'}_kernel<false>"}.get(dom, dom)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.isfile(pmc_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1:
+        with open(pmc_path) as fh:
+            traffic = json.load(fh).get(symbol, {}).get("hbm_bytes_per_launch")
+    mfma_bound = dom in ("qkv", "fc1", "attention", "patch_embed", "gram_argmax", "linear_partial(proj+fc2)")
     if mfma_bound:
         peak = PEAK_MFMA["fp32" if dom == "gram_argmax" else args.precision]
-        roof = dict(kernel=dom, bound="mfma", achieved=round(fl / avg_s / 1e12, 3), peak=peak / 1e12, unit="TFLOP/s",
-                    frac=round(fl / avg_s / peak, 5), traffic=None,
-                    algorithmic_flops_per_launch=fl, avg_launch_us=kernels[dom]["avg_us"])
+        roof = dict(kernel=symbol, classes=members, bound="mfma", achieved=round(fl / avg_s / 1e12, 3), peak=peak / 1e12,
+                    unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic,
+                    algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
+                    avg_launch_us=round(avg_s * 1e6, 3), event_pair_overhead_us=round(overhead_s * 1e6, 3))
     else:
-        roof = dict(kernel=dom, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9, unit="GB/s",
-                    frac=round(by / avg_s / PEAK_HBM, 5), traffic=None,
-                    algorithmic_bytes_per_launch=by, avg_launch_us=kernels[dom]["avg_us"])
+        roof = dict(kernel=symbol, classes=members, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9,
+                    unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=by, avg_launch_us=round(avg_s * 1e6, 3),
+                    event_pair_overhead_us=round(overhead_s * 1e6, 3))
 
     out = dict(
         metric="servo_updates_per_sec", value=round(value, 2), unit="updates/s", n_gpus=world, steps=args.steps,
