@@ -341,3 +341,68 @@ def test_host_pointer_entry_point_matches_device_entry_point():
                                         p(depth), p(K), _lib.SELECT_DENSE, None, None, p(v), p(st))
     assert rc == 0 and int(st[0]) == int(sd_[0])
     assert np.array_equal(v, vd.cpu().numpy()[0])
+
+
+# ----------------------------------------------------------------------------- host mirror of the reference interface
+def test_controller_adapter_reproduces_reference_update():
+    """Controller.detect_features()/ibvs() with the reference's RNG procedure == the golden v_c (drop-in check)."""
+    from vitvs_amd import servo
+    key = "vits16_224"
+    blob = load_golden(f"e2e_{key}.npz")
+    case = golden_case(blob, "plain")
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=4).load_state_dict(sd)
+    ctl = servo.Controller(eng, goal_image=des, selection="reference")
+    assert ctl.detect_features() == (None, None)          # no image yet
+    ctl.image_callback_rgb(cur)
+    ctl.image_callback_depth(synth.depth_pattern())
+    torch.manual_seed(121)                                 # reference: vitvs_v2.py:1397
+    (s_uv_star, s_uv), sim = ctl.detect_features()
+    assert np.array_equal(s_uv, case["s_uv"]) and np.array_equal(s_uv_star, case["s_uv_star"])
+    np.testing.assert_allclose(sim.numpy().reshape(-1), case["sim_selected"], atol=2e-5)
+    torch.manual_seed(121)
+    ctl.ibvs()
+    assert _rel_l2(ctl.v_c, case["ema_first"]) <= 1e-9     # first EMA sample == raw v_c
+    lin, ang = ctl.publish_twist()
+    assert lin == pytest.approx((ctl.v_c[2], -ctl.v_c[0], -ctl.v_c[1]))
+    # order selection: every chosen token is a mutual NN and v_c stays a sane twist
+    v, st = servo.compute_velocity(eng, cur, des, synth.depth_pattern(), selection="order",
+                                   generator=torch.Generator().manual_seed(5))
+    det = eng.last_details(1)
+    mutual = set(np.nonzero(case["nn_2"][case["nn_1"]] == np.arange(cfg.tokens))[0].tolist())
+    assert st == 0 and set(det["selected"][0, :params.num_pairs].tolist()) <= mutual and np.all(np.isfinite(v))
+    # rotation compensation: the un-rotated view must score best against the goal
+    cands = [np.rot90(cur, k).copy() for k in (1, 0, 2, 3)]
+    best, scores = ctl.best_rotation(cands)
+    assert best == 1 and len(scores) == 4
+
+
+def test_controller_failure_counter_raises_like_the_reference():
+    from vitvs_amd import servo
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd)
+    des, _ = synth.frame_pair(224, 1)
+    # distinct flat frames: every token of a frame is identical up to position, all arg-maxes collapse ...
+    ctl = servo.Controller(eng, goal_image=des, selection="reference")
+    ctl.image_callback_rgb(des)                             # identical frames -> same-image shortcut, status ok
+    ctl.image_callback_depth(synth.depth_pattern())
+    assert ctl.detect_features()[0] is not None
+    ctl.last_status = None
+    # force the failure path through the status code the kernel reports for "all tokens mutual"
+    import types
+    def fake_cv(engine, *a, **k):
+        return np.zeros(6), _lib.STATUS_NO_CORRESPONDENCE
+    orig = servo.compute_velocity
+    servo.compute_velocity = fake_cv
+    try:
+        for _ in range(9):
+            assert ctl.detect_features() == (None, None)
+        with pytest.raises(RuntimeError, match="Persistent feature detection failure"):
+            ctl.detect_features()
+    finally:
+        servo.compute_velocity = orig

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's interface around the HIP hot path.
+
+Same names, argument meaning and error behaviour as the reference's callables, without ROS:
+
+  compute_velocity(I_cur, I_des, Z, K)        the north-star seam = detect_features() + ibvs() up to the raw
+                                              twist (reference: vitvs_v2.py:464-523, 588-622)
+  find_correspondences_batch(desc1, desc2)    reference: vitvs_v2.py:72-155 (same return shapes, same RNG stream)
+  Controller.detect_features() / .ibvs()      reference: vitvs_v2.py:464-523, 588-632 (EMA :325-343, failure
+                                              counter :500-505, twist remap :661-676)
+  Controller.best_rotation(frames)            reference: find_and_set_best_pose, vitvs_v2.py:1151-1189
+
+All arithmetic of the path runs on the GPU through ``Engine`` (C ABI); what stays on the host is what the
+reference also does on the host: PIL resize, the RNG draw, the EMA state and the twist remap.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ServoParams
+from .engine import Engine
+
+STATUS_NAMES = {0: "ok", 1: "no_correspondence", 2: "too_few_features", 3: "no_depth"}
+
+
+# ------------------------------------------------------------------------------------------ functional API
+def compute_velocity(engine: Engine, I_cur, I_des, Z, K=None, *, selection="order",
+                     generator: Optional[torch.Generator] = None):
+    """One servo update for one frame pair: raw (pre-EMA) ``v_c`` float64[6] and a status int.
+
+    ``I_cur`` / ``I_des``: uint8 RGB frames already at the extractor's input size (the reference resizes with
+    PIL before the path); ``Z``: the sensor's uint16 millimetre depth image; ``K`` = (fx, fy, cx, cy), default
+    from the engine's parameters.  ``selection``:
+      "order"      a fresh random visiting order (CPU generator); the first num_pairs mutual-NN tokens met are used,
+                   everything stays on the device (one graph replay)
+      "reference"  the reference's exact procedure and RNG stream (torch sort + randperm on the host between the
+                   correspondence and the control law; two device round trips, as in the reference)
+      "dense"      every mutual-NN token
+      array-like   explicit token ids of the desired frame
+    """
+    v, st = compute_velocity_batch(engine, np.asarray(I_cur)[None], np.asarray(I_des)[None],
+                                   None if Z is None else np.asarray(Z)[None], K, selection=selection,
+                                   generator=generator)
+    return v[0], int(st[0])
+
+
+def compute_velocity_batch(engine: Engine, I_cur, I_des, Z, K=None, *, selection="order", des_shared: bool = False,
+                           generator: Optional[torch.Generator] = None):
+    """``B`` pairs in one call → (v_c float64 [B,6], status int32 [B]) as numpy arrays."""
+    p = engine.params
+    K = p.intrinsics() if K is None else K
+    n = np.asarray(I_cur).shape[0]
+    if isinstance(selection, str) and selection == "reference":
+        if n != 1:
+            raise ValueError('selection="reference" follows the reference: one pair per call')
+        return _reference_update(engine, I_cur, I_des, Z, K, generator)
+    if isinstance(selection, str) and selection == "order":
+        order = torch.stack([torch.randperm(engine.tokens, generator=generator) for _ in range(n)]).to(torch.int32)
+        v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_ORDER, selection=order,
+                                        des_shared=des_shared)
+    elif isinstance(selection, str) and selection == "dense":
+        v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_DENSE, des_shared=des_shared)
+    else:
+        ids = selection if isinstance(selection, (list, tuple)) and n > 1 else [selection]
+        v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_EXPLICIT, selection=list(ids),
+                                        des_shared=des_shared)
+    return v.cpu().numpy(), st.cpu().numpy()
+
+
+def _candidate_order(nn_1: torch.Tensor, nn_2: torch.Tensor, grid: int, distance_threshold: float = 1.0):
+    """Tokens that pass the reference's cyclic-consistency filter, in the order its descending sort leaves them
+    (so that a following ``randperm`` picks the same tokens as the reference does with the same seed)."""
+    t = nn_1.numel()
+    back = nn_2[nn_1]                                    # where each token's best match points back to
+    here = torch.arange(t)
+    delta = torch.stack((back // grid - here // grid, back % grid - here % grid), dim=-1)
+    dist = -torch.linalg.vector_norm((delta + 1e-6).to(torch.float32), 2, dim=-1)
+    spread = dist - dist.min()
+    spread = spread / (spread.max() + 1e-8)
+    vals, order = spread.sort(dim=-1, descending=True)
+    return order[vals >= distance_threshold]
+
+
+def find_correspondences_batch(engine: Engine, descriptors1: torch.Tensor, descriptors2: torch.Tensor,
+                               num_pairs: int = 18, distance_threshold: float = 1):
+    """Drop-in for the reference function: descriptors ``[1,1,T,D']`` → ``(points1, points2, sim)`` with
+    ``points*`` int64 ``[K,2]`` (row, col) and ``sim`` ``[1,K]``, or ``(None, None, None)``.
+    Similarities and arg-maxes run on the GPU; the draw uses torch's global CPU RNG like the reference."""
+    d1 = descriptors1.reshape(-1, descriptors1.shape[-1])
+    d2 = descriptors2.reshape(-1, descriptors2.shape[-1])
+    t = d1.shape[0]
+    grid = int(np.sqrt(t))
+    nn_1, nn_2, sim_1 = (x.cpu() for x in engine.correspond(d1, d2))
+    nn_1, nn_2 = nn_1.long(), nn_2.long()
+    rc = lambda idx: torch.stack((idx // grid, idx % grid), dim=-1)  # noqa: E731
+    if sim_1.mean().item() > 0.99:                       # same-image shortcut
+        k = min(num_pairs, t)
+        pts = rc(torch.randperm(t)[:k])
+        return pts, pts.clone(), torch.ones(k)
+    cand = _candidate_order(nn_1, nn_2, grid, distance_threshold)
+    k = min(num_pairs, cand.numel())
+    if k == 0:
+        return None, None, None
+    chosen = cand[torch.randperm(cand.numel())[:k]]
+    return rc(chosen), rc(nn_1[chosen]), sim_1[chosen].unsqueeze(0)
+
+
+def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator):
+    frames = np.concatenate([np.asarray(I_des), np.asarray(I_cur)])
+    desc = engine.extract_descriptors(frames)
+    if generator is not None:
+        state = torch.get_rng_state()
+        torch.set_rng_state(generator.get_state())
+    try:
+        p1, _, _ = find_correspondences_batch(engine, desc[0:1], desc[1:2], num_pairs=engine.params.num_pairs)
+    finally:
+        if generator is not None:
+            generator.set_state(torch.get_rng_state())
+            torch.set_rng_state(state)
+    if p1 is None:
+        return np.zeros((1, 6)), np.array([_lib.STATUS_NO_CORRESPONDENCE], np.int32)
+    ids = (p1[:, 0] * engine.cfg.grid + p1[:, 1]).to(torch.int32)
+    v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_EXPLICIT, selection=[ids])
+    return v.cpu().numpy(), st.cpu().numpy()
+
+
+def ema_update(state: list, v: Sequence[float], alpha: float) -> np.ndarray:
+    """Per-component exponential moving average with the reference's first-sample initialisation."""
+    out = np.empty(6)
+    for i, x in enumerate(np.asarray(v, dtype=np.float64).reshape(6)):
+        state[i] = x if state[i] is None else alpha * x + (1 - alpha) * state[i]
+        out[i] = state[i]
+    return out
+
+
+def twist_from_velocity(v_c, max_velocity: float):
+    """Camera optical frame → (linear xyz, angular xyz) as the reference publishes them (clipped)."""
+    c = lambda x: float(min(max(x, -max_velocity), max_velocity))  # noqa: E731
+    return (c(v_c[2]), c(-v_c[0]), c(-v_c[1])), (c(v_c[5]), c(-v_c[3]), c(-v_c[4]))
+
+
+# ------------------------------------------------------------------------------------------ Controller adapter
+class Controller:
+    """ROS-free stand-in for the reference ``Controller``'s hot-path half: feed it frames, call ``ibvs()``
+    in the control loop, read ``v_c``.  Attribute names follow the reference so its ``run()`` logic ports 1:1."""
+
+    def __init__(self, engine: Engine, goal_image, params: Optional[ServoParams] = None,
+                 selection: str = "reference"):
+        self.engine = engine
+        self.params = params or engine.params
+        self.num_pairs = self.params.num_pairs
+        self.dino_input_size = engine.cfg.img_size
+        self.goal_image = goal_image                      # PIL image or uint8 array, any size
+        self.latest_image = None                          # uint8 HxWx3 RGB (the reference keeps BGR + a PIL copy)
+        self.latest_pil_image = None
+        self.latest_image_depth = None                    # uint16 millimetres, v_max x u_max
+        self.selection = selection
+        self.feature_failure_count = 0
+        self.ema_velocities = [None] * 6
+        self.v_c = np.zeros(6)
+        self.velocity_vector_history = []
+        self.last_status = None
+
+    # -- inputs (the reference's ROS callbacks)
+    def image_callback_rgb(self, rgb_u8):
+        self.latest_image = np.asarray(rgb_u8)
+        self.latest_pil_image = self.latest_image
+
+    def image_callback_depth(self, depth_u16):
+        self.latest_image_depth = np.asarray(depth_u16)
+
+    def _resized(self, img) -> np.ndarray:
+        """PIL resize to the extractor input (default filter: bicubic), as the reference does before the path."""
+        from PIL import Image
+        s = self.dino_input_size
+        pil = img if hasattr(img, "resize") and not isinstance(img, np.ndarray) else Image.fromarray(np.asarray(img))
+        if pil.size != (s, s):
+            pil = pil.resize((s, s))
+        return np.asarray(pil.convert("RGB"), dtype=np.uint8)
+
+    # -- the hot path
+    def detect_features(self):
+        """→ ((s_uv_star, s_uv), sim_selected) with int arrays [num_pairs,2] in camera pixels, or (None, None).
+        The 10th consecutive failure raises RuntimeError("Persistent feature detection failure")."""
+        if self.latest_image is None:
+            return None, None
+        cur, des = self._resized(self.latest_pil_image), self._resized(self.goal_image)
+        depth = self.latest_image_depth
+        # the law needs a depth image; detect_features itself does not, so feed a dummy one if it is missing
+        z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
+        v, st = compute_velocity(self.engine, cur, des, z, self.params.intrinsics(), selection=self.selection)
+        self._raw_v, self.last_status = v, st
+        if st == _lib.STATUS_NO_CORRESPONDENCE:
+            self.feature_failure_count += 1
+            if self.feature_failure_count >= 10:
+                raise RuntimeError("Persistent feature detection failure")
+            return None, None
+        self.feature_failure_count = 0
+        det = self.engine.last_details(1)
+        k = self.num_pairs
+        s_uv_star = det["s_uv"][0, :k, 0:2].astype(int)
+        s_uv = det["s_uv"][0, :k, 2:4].astype(int)
+        n_matched = int(det["info"][0, 3])
+        sim = torch.from_numpy(det["feat"][0, :max(n_matched, 0), 3].astype(np.float32)).unsqueeze(0)
+        return (s_uv_star, s_uv), sim
+
+    def ibvs(self):
+        """One control-law step: updates ``self.v_c`` (EMA-smoothed) or leaves it untouched on failure."""
+        if self.latest_image is None:
+            return
+        result = self.detect_features()
+        if result is None or result[0] is None:
+            return
+        if self.latest_image_depth is None:               # reference: "Failed to get depth - skipping"
+            return
+        self.v_c = ema_update(self.ema_velocities, self._raw_v, self.params.ema_alpha)
+        self.velocity_vector_history.append(self.v_c)
+
+    def publish_twist(self, v_c=None):
+        return twist_from_velocity(self.v_c if v_c is None else v_c, self.params.max_velocity)
+
+    # -- rotation compensation: 4 (or any number of) candidate views against the one goal image
+    def best_rotation(self, candidate_frames: Sequence):
+        """Index of the candidate current frame whose selected correspondences are most similar on average
+        (reference: score = sim_selected_12.mean(), with num_pairs = 48 there — build the engine with the
+        num_pairs you want scored), evaluated as ONE batch sharing the goal forward."""
+        eng = self.engine
+        if eng.max_pairs < len(candidate_frames):
+            raise ValueError("engine.max_pairs is smaller than the number of candidates")
+        cur = np.stack([self._resized(f) for f in candidate_frames])
+        des = self._resized(self.goal_image)[None]
+        z = np.zeros((len(cur), self.params.v_max, self.params.u_max), np.uint16)
+        order = torch.stack([torch.randperm(eng.tokens) for _ in range(len(cur))]).to(torch.int32)
+        eng.compute_velocity(cur, des, z, self.params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
+                             des_shared=True)
+        det = eng.last_details(len(cur))
+        scores = []
+        for b in range(len(cur)):
+            n = int(det["info"][b, 3])
+            scores.append(float(det["feat"][b, :n, 3].mean()) if n > 0 else -np.inf)
+        return int(np.argmax(scores)), scores
