@@ -35,6 +35,13 @@ def gather_velocities(v_local: torch.Tensor, n_pairs: int, group=None, out: torc
     b, e = sizes[rank]
     if v_local.shape != (e - b, 6):
         raise ValueError(f"rank {rank} should hold {(e - b, 6)}, got {tuple(v_local.shape)}")
+    if v_local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (several ranks sharing one GPU, gloo): stage the 48-byte rows through the host
+        full_cpu = gather_velocities(v_local.detach().cpu(), n_pairs, group)
+        if out is not None:
+            out.copy_(full_cpu)
+            return out
+        return full_cpu.to(v_local.device)
     if all(e2 - b2 == n_max for b2, e2 in sizes):
         full = out if out is not None else torch.empty((n_pairs, 6), dtype=v_local.dtype, device=v_local.device)
         dist.all_gather_into_tensor(full, v_local.contiguous(), group=group)
