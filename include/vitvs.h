@@ -145,10 +145,10 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
                        int32_t* selected, int32_t* s_uv, double* feat, double* L);
 
 /* --- measurement hooks (bench.py roofline leg) --------------------------------------------------
- * With timing enabled every kernel launch of the path is bracketed by a HIP event pair on the launch
- * stream (and hipGraph replay is bypassed).  vitvs_timing_collect synchronises and returns, per
- * kernel class, the summed event-to-event milliseconds and the number of launches since the last
- * collect; class names come from vitvs_timing_class_name(0 .. vitvs_timing_classes()-1). */
+ * With timing enabled every kernel of the path is dispatched with a HIP event pair that the dispatch
+ * itself stamps with its begin / end times (hipExtLaunchKernelGGL on the launch stream; hipGraph replay
+ * is bypassed).  vitvs_timing_collect synchronises and returns, per kernel class, the summed kernel
+ * milliseconds and the number of launches since the last collect; class names come from vitvs_timing_class_name(0 .. vitvs_timing_classes()-1). */
 VITVS_API int vitvs_timing_enable(vitvs_handle* h, int32_t on);
 VITVS_API int vitvs_timing_classes(void);
 VITVS_API const char* vitvs_timing_class_name(int32_t cls);

@@ -18,6 +18,7 @@
 namespace vitvs {
 
 static thread_local std::string g_last_error;
+thread_local LaunchTiming g_launch_timing;
 
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
@@ -38,6 +39,9 @@ struct Block {
     float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
     float *qkvb = nullptr, *projb = nullptr, *fc1b = nullptr, *fc2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
     void *qkvw = nullptr, *projw = nullptr, *fc1w = nullptr, *fc2w = nullptr;
+    // fused-LayerNorm path: gamma-folded weights and the c1 / c2 epilogue vectors (gemm_fused.hip)
+    void *qkvw_f = nullptr, *fc1w_f = nullptr;
+    float *qkv_c1 = nullptr, *qkv_c2 = nullptr, *fc1_c1 = nullptr, *fc1_c2 = nullptr;
 };
 
 }  // namespace vitvs
@@ -55,6 +59,11 @@ struct vitvs_handle {
     std::string err;
     std::vector<void*> allocs;
     std::map<std::string, bool> have;
+    std::map<std::string, std::vector<float>> stash;   // host copies of the tensors the LayerNorm folding needs
+    bool fused_ln = true, folded = false;
+    bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
+    void* xb = nullptr;       // residual stream in the GEMM operand type (bf16 mode), [M][D]
+    float* stats = nullptr;   // per-row partial moments [M][D/16][2]
     // weights
     std::vector<Block> blk;
     void* pe_w = nullptr;
@@ -164,20 +173,61 @@ int check_cfg(const vitvs_config* c, std::string& why) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// W'[n][k] = gamma[k] W[n][k] (uploaded in the operand type), c1[n] = sum_k W'[n][k] as the GEMM will see it
+// (after rounding to the operand type), c2[n] = sum_k beta[k] W[n][k] + bias[n].  See gemm_fused.hip.
+int fold_one(vitvs_handle* h, const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gamma,
+             const std::vector<float>& beta, size_t N, size_t K, void** wf, float** c1, float** c2) {
+    std::vector<float> Wf(N * K), v1(N), v2(N);
+    for (size_t n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+            float w = W[n * K + k] * gamma[k];
+            Wf[n * K + k] = w;
+            if (h->prec == PREC_BF16) {
+                const uint32_t bits = (uint32_t)f32_to_bf16_host(w) << 16;
+                memcpy(&w, &bits, 4);
+            }
+            s1 += (double)w;
+            s2 += (double)beta[k] * (double)W[n * K + k];
+        }
+        v1[n] = (float)s1;
+        v2[n] = (float)(s2 + (double)bias[n]);
+    }
+    int rc = upload_matrix(h, wf, Wf.data(), N, K, K);
+    if (!rc) rc = upload_f32(h, c1, v1.data(), N);
+    if (!rc) rc = upload_f32(h, c2, v2.data(), N);
+    return rc;
+}
+
+int fold_layernorms(vitvs_handle* h) {
+    const size_t D = h->cfg.dim, H4 = h->hidden;
+    for (int i = 0; i < h->cfg.blocks; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        Block& blk = h->blk[i];
+        int rc = fold_one(h, h->stash[b + "attn.qkv.weight"], h->stash[b + "attn.qkv.bias"], h->stash[b + "norm1.weight"],
+                          h->stash[b + "norm1.bias"], 3 * D, D, &blk.qkvw_f, &blk.qkv_c1, &blk.qkv_c2);
+        if (!rc)
+            rc = fold_one(h, h->stash[b + "mlp.fc1.weight"], h->stash[b + "mlp.fc1.bias"], h->stash[b + "norm2.weight"],
+                          h->stash[b + "norm2.bias"], H4, D, &blk.fc1w_f, &blk.fc1_c1, &blk.fc1_c2);
+        if (rc) return set_err(h, rc, "LayerNorm folding failed for block " + std::to_string(i));
+    }
+    return 0;
+}
+
 enum KernelClass : int {
     KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
-    KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_NULL, KC_COUNT
+    KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_COUNT
 };
 const char* const kClassNames[KC_COUNT] = {"patchify", "patch_embed", "layernorm", "qkv", "attention", "proj",
                                            "fc1", "fc2", "descriptors", "gram_argmax", "servo",
-                                           "residual_ln", "null_span"};
+                                           "residual_ln"};
 
-// Brackets one launch with a HIP event pair on its stream when timing is enabled.
+// When timing is enabled, arms the launch helper (kernels.h) so that the next kernel launched inside the span
+// is dispatched with an event pair stamped with its own begin / end times.
 struct Span {
     vitvs_handle* h;
-    hipStream_t st;
-    hipEvent_t stop = nullptr;
-    Span(vitvs_handle* h_, int cls, hipStream_t st_) : h(h_), st(st_) {
+    bool armed = false;
+    Span(vitvs_handle* h_, int cls, hipStream_t) : h(h_) {
         if (!h->timing) return;
         if (h->ev_used + 2 > h->ev_pool.size()) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -185,14 +235,18 @@ struct Span {
             h->ev_pool.push_back(a);
             h->ev_pool.push_back(b);
         }
-        hipEvent_t start = h->ev_pool[h->ev_used];
-        stop = h->ev_pool[h->ev_used + 1];
+        g_launch_timing.start = h->ev_pool[h->ev_used];
+        g_launch_timing.stop = h->ev_pool[h->ev_used + 1];
         h->ev_used += 2;
         h->ev_class.push_back(cls);
-        (void)hipEventRecord(start, st);
+        armed = true;
     }
     ~Span() {
-        if (stop) (void)hipEventRecord(stop, st);
+        if (armed && g_launch_timing.start) {   // nothing was launched inside the span: drop the pair
+            g_launch_timing = LaunchTiming{};
+            h->ev_used -= 2;
+            h->ev_class.pop_back();
+        }
     }
 };
 
@@ -219,7 +273,35 @@ int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
     for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
     pa.cls = h->cls; pa.pos = h->pos;
+    pa.xb = nullptr; pa.stats = nullptr;
     int rc;
+    if (h->fused_ln) {
+        // 5 launches per block: the LayerNorms live in the GEMM epilogues (gemm_fused.hip)
+        unsigned char* xb = (h->prec == PREC_BF16) ? (unsigned char*)h->xb + row0 * D * es : nullptr;
+        float* stats = h->stats + row0 * (D / 16) * 2;
+        const void* a_op = xb ? (const void*)xb : (const void*)x;   // operand of the qkv / fc1 GEMMs
+        pa.xb = xb; pa.stats = stats;
+        { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, Ape, x, st); }
+        if (rc) return set_err(h, rc, "patchify launch failed");
+        { Span sp(h, KC_PATCH_EMBED, st);
+          rc = launch_patch_embed_stats(h->prec, Ape, h->pe_w, h->pe_b, h->pos, x, xb, stats, cnt, h->T, D, h->Kp, st); }
+        if (rc) return set_err(h, rc, "patch-embed launch failed");
+        for (int i = 0; i < c.blocks; ++i) {
+            const Block& b = h->blk[i];
+            { Span sp(h, KC_QKV, st);
+              rc = launch_linear_ln(h->prec, a_op, b.qkvw_f, b.qkv_c1, b.qkv_c2, stats, D, qkv, M, 3 * D, D, 0, c.ln_eps, st); }
+            if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, qkv, attn, cnt, h->N, c.heads, st); }
+            if (!rc) { Span sp(h, KC_PROJ, st);
+                       rc = launch_linear_residual_stats(h->prec, attn, b.projw, b.projb, b.ls1, x, xb, stats, M, D, D, st); }
+            if (!rc) { Span sp(h, KC_FC1, st);
+                       rc = launch_linear_ln(h->prec, a_op, b.fc1w_f, b.fc1_c1, b.fc1_c2, stats, D, hid, M, h->hidden, D, 1,
+                                             c.ln_eps, st); }
+            if (!rc) { Span sp(h, KC_FC2, st);
+                       rc = launch_linear_residual_stats(h->prec, hid, b.fc2w, b.fc2b, b.ls2, x, xb, stats, M, D, h->hidden, st); }
+            if (rc) return set_err(h, rc, "block launch failed");
+        }
+        return 0;
+    }
     { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, Ape, x, st); }
     if (rc) return set_err(h, rc, "patchify launch failed");
     { Span sp(h, KC_PATCH_EMBED, st);
@@ -339,6 +421,11 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     const char* nc = getenv("VITVS_ONE_CHAIN");
     // Off by default: on this platform kernels of different queues were measured to alternate rather
     // than overlap (rocprofv3 timeline, profiles/), so the second chain only adds fork/join cost.
+    // LayerNorm folded into the GEMM epilogues (5 launches per block instead of 7, gemm_fused.hip): correct
+    // and tested, but measured 3-6 % slower at one frame pair (the 84-workgroup fc2 without split-K and the
+    // moment merge in the consumers cost more than the two residual_ln launches save) -> opt-in.
+    const char* fl = getenv("VITVS_FUSED_LN");
+    h->fused_ln = (fl && fl[0] == '1');
     const char* tc = getenv("VITVS_TWO_CHAINS");
     (void)nc;
     h->two_chains = (tc && tc[0] == '1');
@@ -365,6 +452,8 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 #undef ALLOC_BYTES
     if (!rc) rc = dev_alloc(h, &h->x, M * D);
     if (!rc) rc = dev_alloc(h, &h->part, 2 * (size_t)8 * (h->n_img_max / 2 + 1) * h->N * D);
+    if (!rc) { rc = dev_alloc(h, &p8, M * D * es); h->xb = p8; }
+    if (!rc) rc = dev_alloc(h, &h->stats, M * (D / 16) * 2);
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
@@ -465,13 +554,26 @@ int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64
     } else {
         return set_err(h, -6, "unknown tensor " + nm);
     }
-    if (rc == 0) h->have[nm] = true;
+    if (rc == 0) {
+        h->have[nm] = true;
+        h->ready = false;
+        const size_t dot2 = nm.rfind("blocks.", 0) == 0 ? nm.find('.', 7) : std::string::npos;
+        if (dot2 != std::string::npos) {
+            const std::string leaf = nm.substr(dot2 + 1);
+            if (leaf == "norm1.weight" || leaf == "norm1.bias" || leaf == "norm2.weight" || leaf == "norm2.bias" ||
+                leaf == "attn.qkv.weight" || leaf == "attn.qkv.bias" || leaf == "mlp.fc1.weight" || leaf == "mlp.fc1.bias") {
+                h->stash[nm].assign(data, data + numel);
+                h->folded = false;
+            }
+        }
+    }
     return rc;
 }
 
 int vitvs_weights_ready(const vitvs_handle* hc) {
     vitvs_handle* h = const_cast<vitvs_handle*>(hc);
     if (!h) return -1;
+    if (h->ready) return 0;
     std::vector<std::string> need = {"patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token", "pos_embed"};
     static const char* leaves[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
                                    "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
@@ -488,6 +590,12 @@ int vitvs_weights_ready(const vitvs_handle* hc) {
             h->err = "missing tensor " + n;
             return -4;
         }
+    if (h->fused_ln && !h->folded) {
+        int rc = fold_layernorms(h);
+        if (rc) return rc;
+        h->folded = true;
+    }
+    h->ready = true;
     return 0;
 }
 
@@ -575,7 +683,6 @@ static int segment_tail(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
       rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");
     rc = run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.selection, u.n_selected, u.v_c, u.status, st);
-    { Span calib(h, KC_NULL, st); }  // empty event pair: the per-launch cost of the instrumentation itself
     return rc;
 }
 

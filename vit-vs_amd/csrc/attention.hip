@@ -402,17 +402,17 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
         const size_t res = (size_t)(2 * nt + 1) * 64 * 256;
         if (res <= 144 * 1024 && !force_stream) {
             if (launch_attn(attention_f32_kernel<true>, grid, res, stream, qkv, out, N, D, &raised_f32)) return -1;
-            attention_f32_kernel<true><<<grid, block, res, stream>>>((const float*)qkv, (float*)out, N, D);
+            launch(attention_f32_kernel<true>, grid, block, res, stream, (const float*)qkv, (float*)out, N, D);
         } else {
-            attention_f32_kernel<false><<<grid, block, 2 * 64 * 256, stream>>>((const float*)qkv, (float*)out, N, D);
+            launch(attention_f32_kernel<false>, grid, block, 2 * 64 * 256, stream, (const float*)qkv, (float*)out, N, D);
         }
     } else {
         const size_t res = (size_t)(2 * nt + 1) * 64 * 128;
         if (res <= 144 * 1024 && !force_stream) {
             if (launch_attn(attention_bf16_kernel<true>, grid, res, stream, qkv, out, N, D, &raised_bf16)) return -1;
-            attention_bf16_kernel<true><<<grid, block, res, stream>>>((const bf16*)qkv, (bf16*)out, N, D);
+            launch(attention_bf16_kernel<true>, grid, block, res, stream, (const bf16*)qkv, (bf16*)out, N, D);
         } else {
-            attention_bf16_kernel<false><<<grid, block, 2 * 64 * 128, stream>>>((const bf16*)qkv, (bf16*)out, N, D);
+            launch(attention_bf16_kernel<false>, grid, block, 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

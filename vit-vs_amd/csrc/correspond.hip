@@ -128,14 +128,14 @@ __global__ void encode_best_kernel(const int32_t* __restrict__ nn1, const int32_
 
 int launch_decode_best(const unsigned long long* row_best, const unsigned long long* col_best, int T, int32_t* nn1,
                        int32_t* nn2, float* sim1, hipStream_t stream) {
-    hipLaunchKernelGGL(decode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, row_best, col_best, T, nn1, nn2,
+    launch(decode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, row_best, col_best, T, nn1, nn2,
                        sim1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_encode_best(const int32_t* nn1, const int32_t* nn2, const float* sim1, int T, unsigned long long* row_best,
                        unsigned long long* col_best, hipStream_t stream) {
-    hipLaunchKernelGGL(encode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, nn1, nn2, sim1, T, row_best,
+    launch(encode_best_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, nn1, nn2, sim1, T, row_best,
                        col_best);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -148,12 +148,12 @@ int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shar
         // few tokens: 32x32 tiles (49 workgroups at T = 196 instead of 16) with two k-groups
         using Tile = GemmTile<32, 32, 2>;
         dim3 g32((T + 31) / 32, (T + 31) / 32, n_pairs);
-        gram_argmax_kernel<32, 32, 2><<<g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream>>>(dn, T, Dp, n_pairs, des_shared,
+        launch(gram_argmax_kernel<32, 32, 2>, g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, dn, T, Dp, n_pairs, des_shared,
                                                                                        row_best, col_best);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
-    gram_argmax_kernel<64, 64, 1><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, row_best, col_best);
+    launch(gram_argmax_kernel<64, 64, 1>, grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, row_best, col_best);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -161,7 +161,7 @@ int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_share
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
     dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
     constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
-    gram_dense_kernel<64, 64><<<grid, dim3(256), lds, stream>>>(dn, T, Dp, n_pairs, des_shared, S);
+    launch(gram_dense_kernel<64, 64>, grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, S);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -18,8 +18,31 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
     const int row = blockIdx.x;
     if (row >= n_img * Tn) {  // cls rows: x[img][0][:] = cls + pos[0]
         const int img = row - n_img * Tn;
-        float* dst = x + (size_t)img * (Tn + 1) * a.D;
-        for (int d = threadIdx.x; d < a.D; d += blockDim.x) dst[d] = a.cls[d] + a.pos[d];
+        const size_t xrow = (size_t)img * (Tn + 1);
+        float* dst = x + xrow * a.D;
+        if (!a.stats) {
+            for (int d = threadIdx.x; d < a.D; d += blockDim.x) dst[d] = a.cls[d] + a.pos[d];
+            return;
+        }
+        // fused-LayerNorm path: also the operand-typed copy and the per-16-column partial moments
+        T* xb = a.xb ? reinterpret_cast<T*>(a.xb) + xrow * a.D : nullptr;
+        const int np = a.D >> 4;
+        for (int p = threadIdx.x; p < np; p += blockDim.x) {
+            float v[16], s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v[j] = a.cls[16 * p + j] + a.pos[16 * p + j];
+                s += v[j];
+                dst[16 * p + j] = v[j];
+                if (xb) xb[16 * p + j] = from_float<T>(v[j]);
+            }
+            const float mean = s * 0.0625f;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) q += (v[j] - mean) * (v[j] - mean);
+            a.stats[(xrow * np + p) * 2 + 0] = s;
+            a.stats[(xrow * np + p) * 2 + 1] = q;
+        }
         return;
     }
     const int img = row / Tn, t = row - img * Tn;
@@ -46,9 +69,9 @@ int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hip
     const int rows = n_img * a.grid * a.grid + n_img;
     if (rows <= 0 || a.Kp < 3 * a.patch * a.patch) return -2;
     if (p == PREC_F32)
-        hipLaunchKernelGGL(patchify_kernel<float>, dim3(rows), dim3(256), 0, stream, a, (float*)Ape, x);
+        launch(patchify_kernel<float>, dim3(rows), dim3(256), 0, stream, a, (float*)Ape, x);
     else
-        hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(rows), dim3(256), 0, stream, a, (bf16*)Ape, x);
+        launch(patchify_kernel<bf16>, dim3(rows), dim3(256), 0, stream, a, (bf16*)Ape, x);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -102,11 +125,11 @@ static int launch_ln_t(const float* x, const float* g, const float* b, T* out, i
                        hipStream_t stream) {
     dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
     switch (D) {
-        case 384: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, stream, x, g, b, out, M, eps); break;
-        case 768: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, stream, x, g, b, out, M, eps); break;
-        case 1024: hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, block, 0, stream, x, g, b, out, M, eps); break;
-        case 128: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, stream, x, g, b, out, M, eps); break;
-        case 256: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, stream, x, g, b, out, M, eps); break;
+        case 384: launch((layernorm_kernel<T, 3>), grid, block, 0, stream, x, g, b, out, M, eps); break;
+        case 768: launch((layernorm_kernel<T, 6>), grid, block, 0, stream, x, g, b, out, M, eps); break;
+        case 1024: launch((layernorm_kernel<T, 8>), grid, block, 0, stream, x, g, b, out, M, eps); break;
+        case 128: launch((layernorm_kernel<T, 1>), grid, block, 0, stream, x, g, b, out, M, eps); break;
+        case 256: launch((layernorm_kernel<T, 2>), grid, block, 0, stream, x, g, b, out, M, eps); break;
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -123,83 +146,81 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
 // Finishes a split-K linear layer: x += ls * (sum_z part[z] + bias), slices summed in index order,
 // then (optionally) the next LayerNorm of the freshly updated row — one pass, one wave per row.
 // Reference: dino_patch/block.py:90-96,112-115 (x + ls(f(norm(x)))), followed by the next norm.
+// A row is D/4 float4; lane l < LANES owns float4 l, l + LANES, ... (NV4 of them): 16-byte accesses, every
+// load of the row (x, every slice, the four parameter vectors) issued before the first add.
 constexpr int SMAX = 8;  // most K slices splitk_slices() ever picks
 
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void residual_ln_kernel(float* __restrict__ x, const float* __restrict__ part,
-                                                          int splits, const float* __restrict__ bias,
-                                                          const float* __restrict__ ls, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, T* __restrict__ out, int M,
-                                                          float eps) {
-    constexpr int D = 128 * NV;
+template <typename T, int NV4, int LANES>
+__global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, const float* __restrict__ part,
+                                                         int splits, const float* __restrict__ bias,
+                                                         const float* __restrict__ ls, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ out, int M,
+                                                         float eps) {
+    constexpr int D = 4 * NV4 * LANES;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float2* xr = reinterpret_cast<float2*>(x + (size_t)row * D);
-    const float2* b2 = reinterpret_cast<const float2*>(bias);
-    const float2* l2 = reinterpret_cast<const float2*>(ls);
-    // All loads of the row (x and every K slice) are issued before the first add, so the pass costs one
-    // memory latency, not one per slice; the slices are still summed in index order (deterministic).
-    float2 v[NV], pv[SMAX][NV];
+    const int row = blockIdx.x;
+    const bool on = lane < LANES;
+    const int l = on ? lane : 0;
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
+    float4 v[NV4], pv[SMAX][NV4], bb[NV4], ll[NV4], gg[NV4], be[NV4];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * LANES + l;
+        v[i] = xr[c];
+        bb[i] = reinterpret_cast<const float4*>(bias)[c];
+        if (ls) ll[i] = reinterpret_cast<const float4*>(ls)[c];
+        if (gamma) {
+            gg[i] = reinterpret_cast<const float4*>(gamma)[c];
+            be[i] = reinterpret_cast<const float4*>(beta)[c];
+        }
+    }
 #pragma unroll
     for (int z = 0; z < SMAX; ++z)
         if (z < splits) {
-            const float2* pz = reinterpret_cast<const float2*>(part + ((size_t)z * M + row) * D);
+            const float4* pz = reinterpret_cast<const float4*>(part + ((size_t)z * M + row) * D);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) pv[z][i] = pz[i * 64 + lane];
+            for (int i = 0; i < NV4; ++i) pv[z][i] = pz[i * LANES + l];
         }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 64 + lane;
-        float2 acc = pv[0][i];
+    for (int i = 0; i < NV4; ++i) {
+        float4 acc = pv[0][i];
 #pragma unroll
         for (int z = 1; z < SMAX; ++z)
             if (z < splits) {
-                acc.x += pv[z][i].x;
-                acc.y += pv[z][i].y;
+                acc.x += pv[z][i].x; acc.y += pv[z][i].y; acc.z += pv[z][i].z; acc.w += pv[z][i].w;
             }
-        const float2 b = b2[c];
-        acc.x += b.x;
-        acc.y += b.y;
-        if (ls) {
-            const float2 g = l2[c];
-            acc.x *= g.x;
-            acc.y *= g.y;
-        }
-        float2 r = v[i];
-        r.x += acc.x;
-        r.y += acc.y;
-        xr[c] = r;
+        acc.x += bb[i].x; acc.y += bb[i].y; acc.z += bb[i].z; acc.w += bb[i].w;
+        if (ls) { acc.x *= ll[i].x; acc.y *= ll[i].y; acc.z *= ll[i].z; acc.w *= ll[i].w; }
+        float4 r = v[i];
+        r.x += acc.x; r.y += acc.y; r.z += acc.z; r.w += acc.w;
+        if (on) xr[i * LANES + l] = r;
         v[i] = r;
-        s += r.x + r.y;
+        if (on) s += (r.x + r.y) + (r.z + r.w);
     }
     if (!gamma) return;
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float a = v[i].x - mean, b = v[i].y - mean;
-        q += a * a + b * b;
+    for (int i = 0; i < NV4; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        if (on) q += (a * a + b * b) + (c * c + d * d);
     }
     const float var = wave_sum(q) / (float)D;
     const float rstd = 1.0f / sqrtf(var + eps);
-    const float2* g2 = reinterpret_cast<const float2*>(gamma);
-    const float2* be2 = reinterpret_cast<const float2*>(beta);
+    if (!on) return;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float2 g = g2[i * 64 + lane], b = be2[i * 64 + lane];
-        const float y0 = (v[i].x - mean) * rstd * g.x + b.x;
-        const float y1 = (v[i].y - mean) * rstd * g.y + b.y;
-        T* dst = out + (size_t)row * D + 2 * (i * 64 + lane);
+    for (int i = 0; i < NV4; ++i) {
+        const float y0 = (v[i].x - mean) * rstd * gg[i].x + be[i].x;
+        const float y1 = (v[i].y - mean) * rstd * gg[i].y + be[i].y;
+        const float y2 = (v[i].z - mean) * rstd * gg[i].z + be[i].z;
+        const float y3 = (v[i].w - mean) * rstd * gg[i].w + be[i].w;
+        T* dst = out + (size_t)row * D + 4 * (i * LANES + l);
         if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+            *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
         } else {
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-            bf16x2 h = {(bf16)y0, (bf16)y1};
-            *reinterpret_cast<bf16x2*>(dst) = h;
+            bf16x4 h = {(bf16)y0, (bf16)y1, (bf16)y2, (bf16)y3};
+            *reinterpret_cast<bf16x4*>(dst) = h;
         }
     }
 }
@@ -208,14 +229,14 @@ template <typename T>
 static int launch_rln_t(float* x, const float* part, int splits, const float* bias, const float* ls, const float* g,
                         const float* b, T* out, int M, int D, float eps, hipStream_t stream) {
     dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
-#define VITVS_RLN(NV) \
-    hipLaunchKernelGGL((residual_ln_kernel<T, NV>), grid, block, 0, stream, x, part, splits, bias, ls, g, b, out, M, eps)
+#define VITVS_RLN(NV4, LANES) \
+    launch((residual_ln_kernel<T, NV4, LANES>), grid, block, 0, stream, x, part, splits, bias, ls, g, b, out, M, eps)
     switch (D) {
-        case 128: VITVS_RLN(1); break;
-        case 256: VITVS_RLN(2); break;
-        case 384: VITVS_RLN(3); break;
-        case 768: VITVS_RLN(6); break;
-        case 1024: VITVS_RLN(8); break;
+        case 128: VITVS_RLN(1, 32); break;
+        case 256: VITVS_RLN(1, 64); break;
+        case 384: VITVS_RLN(3, 32); break;
+        case 768: VITVS_RLN(3, 64); break;
+        case 1024: VITVS_RLN(4, 64); break;
         default: return -2;
     }
 #undef VITVS_RLN
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream) {
     if (rows <= 0 || Dp <= 0) return -2;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, src, dst, rows, Dp);
+    launch(normalize_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, src, dst, rows, Dp);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -330,12 +351,12 @@ int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, 
     const int toks = n_img * T;
     if (toks <= 0 || grid * grid != T || zero_count > toks * 64) return -2;
     if (!binned) {
-        hipLaunchKernelGGL(desc_plain_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, dn, raw, n_img, T, D,
+        launch(desc_plain_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, dn, raw, n_img, T, D,
                            zero_a, zero_b, zero_count);
     } else {
-        hipLaunchKernelGGL(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sqnorm_ws, n_img, T, D,
+        launch(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sqnorm_ws, n_img, T, D,
                            zero_a, zero_b, zero_count);
-        hipLaunchKernelGGL(desc_binned_kernel, dim3(toks), dim3(256), 0, stream, x, sqnorm_ws, dn, raw, n_img, T, grid,
+        launch(desc_binned_kernel, dim3(toks), dim3(256), 0, stream, x, sqnorm_ws, dn, raw, n_img, T, grid,
                            D);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -148,25 +148,31 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
     return TilePlan{bn, kg};
 }
 
-template <typename T, int BN, int KG, class Epi>
+template <typename T, int BN, int KG, class Epi, int BM = 64>
 static int launch_one(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream, int splits) {
-    using Tile = GemmTile<64, BN, KG>;
+    using Tile = GemmTile<BM, BN, KG>;
     static bool raised = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, 64, BN, KG, Epi>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES) != hipSuccess)
             return -1;
         raised = true;
     }
-    dim3 grid(N / BN, (M + 63) / 64, splits);
-    linear_kernel<T, 64, BN, KG, Epi><<<grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream>>>(A, W, M, N, K, epi);
+    dim3 grid(N / BN, (M + BM - 1) / BM, splits);
+    launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, M, N, K, epi);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Many-row problems (many frame pairs, 448² / 518² inputs): 128x128 tiles halve the LDS and L2 bytes per MFMA.
+static bool big_problem(int M, int N, int splits) {
+    return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= 512;
 }
 
 template <typename T, class Epi>
 static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
                         int splits = 1, bool fixed64 = false) {
     const int bk = 128 / (int)sizeof(T);
+    if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
@@ -185,6 +191,7 @@ template <typename T, class Epi>
 static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
                           int splits = 1) {
     const int bk = 128 / (int)sizeof(T);
+    if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, true);
     if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
     return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);

@@ -2,6 +2,7 @@
 // All pointers are device pointers; every launch is asynchronous on `stream`.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace vitvs {
@@ -13,6 +14,25 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line);
         hipError_t _e = (expr);                                                        \
         if (_e != hipSuccess) return ::vitvs::fail_hip(_e, #expr, __FILE__, __LINE__); \
     } while (0)
+
+// Kernel timing: when api.hip's Span arms `g_launch_timing`, the NEXT launch goes through
+// hipExtLaunchKernelGGL, which stamps the two events with the dispatch's own begin / end times (what
+// rocprofv3 --kernel-trace reports), so hipEventElapsedTime(start, stop) is that kernel's duration.
+struct LaunchTiming {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchTiming g_launch_timing;
+
+template <typename F, typename... Args>
+inline void launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    if (g_launch_timing.start) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, g_launch_timing.start, g_launch_timing.stop, 0,
+                              args...);
+        g_launch_timing = LaunchTiming{};
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    }
+}
 
 enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
 
@@ -34,6 +54,17 @@ int launch_linear_partial(Precision p, const void* A, const void* W, float* part
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
                        int n_img, int T, int D, int Kp, hipStream_t stream);
 
+// ---- gemm_fused.hip: linear layers with the LayerNorm folded in (see the file header) ---------------
+// out = act(LayerNorm(x) W^T + bias) computed as rstd*(A Wf^T) - rstd*mu*c1 + c2 with A = raw residual stream
+// (operand type), Wf = gamma-folded weight, row moments merged from `stats` ([M][D/16][2]); K must equal D.
+int launch_linear_ln(Precision p, const void* A, const void* Wf, const float* c1, const float* c2, const float* stats,
+                     int D, void* out, int M, int N, int K, int gelu, float eps, hipStream_t stream);
+// x += ls * (A W^T + bias); also writes xb (operand-typed copy, bf16 mode) and the partial moments of the new rows.
+int launch_linear_residual_stats(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
+                                 void* xb, float* stats, int M, int N, int K, hipStream_t stream);
+int launch_patch_embed_stats(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
+                             void* xb, float* stats, int n_img, int T, int D, int Kp, hipStream_t stream);
+
 // ---- elementwise.hip -----------------------------------------------------------------------
 struct PatchifyArgs {
     const uint8_t* des;   // [n_des][S][S][3] RGB u8
@@ -43,6 +74,8 @@ struct PatchifyArgs {
     float mean[3], std[3];
     const float* cls;     // [D]
     const float* pos;     // [1+T][D]
+    void* xb;             // fused-LayerNorm path: operand-typed copy of x (null in fp32 mode / legacy path)
+    float* stats;         // fused-LayerNorm path: [rows][D/16][2] partial moments (null = legacy path)
 };
 // Ape[(img*T + t)][k] = ((u8/255) - mean_c)/std_c for k = c*p*p + py*p + px (zero for k >= 3p²);
 // x[img*(T+1)][:] = cls + pos[0].

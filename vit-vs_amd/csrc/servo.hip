@@ -350,7 +350,7 @@ int launch_servo(const ServoArgs& a, hipStream_t stream) {
     size_t ints = (size_t)3 * a.T + a.max_rows + 8 + 256 + 4;
     size_t lds = ((ints * 4 + 15) & ~(size_t)15) + (size_t)7 * kLdsRows * 8 + 40 * 8;
     if (lds > 64 * 1024) return -3;
-    hipLaunchKernelGGL(servo_kernel, dim3(a.n_pairs), dim3(256), lds, stream, a);
+    launch(servo_kernel, dim3(a.n_pairs), dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
