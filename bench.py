@@ -5,7 +5,7 @@ One "step" = one compute_velocity update per GPU: both frames forwarded through 
 recomputed, as the reference does), dense cosine correspondence, mutual-NN filter, 24 features drawn
 in a fresh random visiting order, interaction matrix, pseudo-inverse -> v_c.  Inputs (frames, depth,
 intrinsics, weights, visiting orders) are resident in HBM before the timed region; each step is
-enqueued without host synchronisation (one hipGraph replay + a 784-byte order copy), and with N > 1
+enqueued without host synchronisation (≈ 90 stream launches + a 784-byte order copy), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--pairs B] [--config KEY]
@@ -21,8 +21,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before HIP initialises (see vit-vs_amd/__init__.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

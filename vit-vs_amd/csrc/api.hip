@@ -416,8 +416,12 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->hidden = 4 * cfg->dim;
     h->n_img_max = 2 * cfg->max_pairs;
     h->blk.resize(cfg->blocks);
-    const char* ng = getenv("VITVS_NO_GRAPH");
-    h->use_graphs = !(ng && ng[0] == '1');
+    // hipGraph replay of the update is opt-in: with kernel arguments in device memory
+    // (HIP_FORCE_DEV_KERNARG=1, set by the Python package before HIP initialises) plain stream launches
+    // measured 2 % FASTER than replaying the captured graph (554 vs 567 us per update), and 18 % slower
+    // than it with host-memory kernargs.
+    const char* ng = getenv("VITVS_GRAPH");
+    h->use_graphs = (ng && ng[0] == '1');
     const char* nc = getenv("VITVS_ONE_CHAIN");
     // Off by default: on this platform kernels of different queues were measured to alternate rather
     // than overlap (rocprofv3 timeline, profiles/), so the second chain only adds fork/join cost.

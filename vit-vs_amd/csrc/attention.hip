@@ -10,6 +10,14 @@
 // scalars, P stays in registers as the B operand of O^T = V^T P^T, and the O^T accumulator again has
 // its query on the lane, so the running rescale is a per-lane multiply.  The MFMA k-slot -> key map
 // is permuted the same way for P and V (any bijection is legal as long as both operands agree).
+//
+// bf16 kernel, KS = 2 ("key split"): at one frame pair there are only 96 workgroups of 4 key tiles, and
+// the tile loop is a serial chain (MFMA -> softmax VALU -> MFMA) at one wave per SIMD.  With KS = 2 a
+// workgroup has 8 waves: waves 0-3 take the first half of the key tiles, waves 4-7 the second half
+// (own LDS stage each), and the two partial (max, sum, O) states are merged through LDS at the end —
+// half the chain length, two waves per SIMD.  Long sequences (many workgroups) use KS = 1.
+// (A variant that kept all K/V of a head resident in LDS, filled by LDS-DMA with counted waits, was
+// measured 1 % slower end to end than this streaming form and was removed: profiles/r01_notes.md.)
 #include <stdlib.h>
 
 #include "common.h"
@@ -17,36 +25,19 @@
 
 namespace vitvs {
 
-// s_waitcnt vmcnt(PER * rem): the immediate must be a constant, so the (wave-uniform) count is dispatched.
-template <int PER>
-__device__ __forceinline__ void wait_copies(int rem) {
-    switch (rem) {
-        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PER) : "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PER) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * PER) : "memory"); break;
-    }
-}
-
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * log2(e), hd = 64
 
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
+
 // ------------------------------------------------------------------------------------ bf16
-// RESIDENT: all keys/values of the (image, head) fit in LDS (N <= 512 in bf16): they are copied once by
-// LDS-DMA (source-side swizzle for K, linear V), one wait, and the tile loop then runs without further
-// global loads or barriers.  Otherwise tiles are streamed through a single 64-key stage.
-template <bool RESIDENT>
-__global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                             int N, int D) {
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                  int N, int D) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int ntiles_all = (N + 63) / 64;
-    unsigned char* ldsK = smem;
-    unsigned char* ldsV = smem + (RESIDENT ? ntiles_all : 1) * 64 * 128;
-    unsigned char* ldsQ = smem + 2 * ntiles_all * 64 * 128;   // RESIDENT only: 64 query rows x 128 B
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = tid >> 6, kgp = wave_all >> 2, wave = wave_all & 3, tl = tid & 255;
+    unsigned char* ldsK = smem + kgp * (2 * 64 * 128);
+    unsigned char* ldsV = ldsK + 64 * 128;
     const int qi = lane & 15, g = lane >> 4;
     const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const size_t ld = (size_t)3 * D;
@@ -57,18 +48,16 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
     const int q = q0 + 16 * wave + qi;
     const int qrow = min(q, N - 1);
     bf16x8 qf[2];
-    if constexpr (!RESIDENT) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ld + 32 * s + 8 * g));
-    }
+    for (int s = 0; s < 2; ++s)
+        qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ld + 32 * s + 8 * g));
 
     f32x4 acc_o[4];
 #pragma unroll
     for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int srow = tid >> 3, schunk = tid & 7;
+    const int srow = tl >> 3, schunk = tl & 7;
     u32x4 rk[2], rv[2];
     auto gload = [&](int kb) {
 #pragma unroll
@@ -78,64 +67,22 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
             rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)key * ld + schunk * 8);
         }
     };
-    const int ntiles = ntiles_all;
-    if constexpr (RESIDENT) {
-        typedef __attribute__((address_space(3))) void* lds_ptr;
-        typedef const __attribute__((address_space(1))) void* gbl_ptr;
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        // 8 KiB per 64-key tile per operand = 8 copy instructions of 1 KiB (8 keys x 128 B) each; every
-        // wave issues, tile by tile, 2 of the K and 2 of the V instructions (4 per tile), so that tile t
-        // has landed when at most 4 * (ntiles - 1 - t) of the wave's copies are still outstanding.
-        // Q goes through LDS as well (this wave's own 16 query rows, 2 copies): with every vector-memory
-        // op an LDS-DMA the compiler inserts no vmcnt of its own, and the counted waits below hold.
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r8 = wv * 2 + j;
-            const int row = r8 * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16* srcp = base + (size_t)min(q0 + row, N - 1) * ld + c * 8;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)srcp, (lds_ptr)(ldsQ + r8 * 1024), 16, 0, 0);
-        }
-        for (int tt = 0; tt < ntiles; ++tt) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool isV = j >= 2;
-                const int r8 = tt * 8 + wv * 2 + (j & 1);            // group of 8 keys
-                const int row = (r8 & 7) * 8 + (lane >> 3);          // row inside its 64-key tile
-                const int key = min(tt * 64 + row, N - 1);
-                const int c = isV ? (lane & 7) : ((lane & 7) ^ ((row >> 1) & 7));
-                const bf16* srcp = (isV ? Vp : Kp) + (size_t)key * ld + c * 8;
-                unsigned char* dstp = (isV ? ldsV : ldsK) + r8 * 1024;
-                __builtin_amdgcn_global_load_lds((gbl_ptr)srcp, (lds_ptr)dstp, 16, 0, 0);
-            }
-        }
-    } else {
-        gload(0);
-    }
-    for (int t = 0; t < ntiles; ++t) {
+    const int ntiles = (N + 63) / 64;
+    const int per_group = (ntiles + KS - 1) / KS;
+    const int first = kgp * per_group;
+    gload(min(first, ntiles - 1) * 64);
+    for (int tt = 0; tt < per_group; ++tt) {
+        const int t = first + tt;
         const int kb = t * 64;
-        if constexpr (!RESIDENT) {
-            __syncthreads();
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<u32x4*>(ldsK + tile128_off(srow + 32 * i, schunk)) = rk[i];
-                *reinterpret_cast<u32x4*>(ldsV + (srow + 32 * i) * 128 + schunk * 16) = rv[i];
-            }
-            __syncthreads();
-            if (t + 1 < ntiles) gload(kb + 64);
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(ldsK + tile128_off(srow + 32 * i, schunk)) = rk[i];
+            *reinterpret_cast<u32x4*>(ldsV + (srow + 32 * i) * 128 + schunk * 16) = rv[i];
         }
-        if constexpr (RESIDENT) {
-            wait_copies<4>(ntiles - 1 - t);
-            __builtin_amdgcn_s_barrier();
-            if (t == 0) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    qf[s] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const u32x4*>(ldsQ + tile128_off(16 * wave + qi, 4 * s + g)));
-            }
-        }
-        const unsigned char* tK = ldsK + (RESIDENT ? t * 64 * 128 : 0);
-        const unsigned char* tV = ldsV + (RESIDENT ? t * 64 * 128 : 0);
+        __syncthreads();
+        if (tt + 1 < per_group) gload(min(t + 1, ntiles - 1) * 64);
+        if (t >= ntiles) continue;   // wave-uniform: this key group has run out of tiles (barriers above still taken)
 
         // S^T tiles: acc_s[t4][r] = S[key = kb + 16*t4 + 4g + r][q]
         f32x4 acc_s[4];
@@ -145,7 +92,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 kf = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(tK + tile128_off(16 * t4 + qi, 4 * s + g)));
+                    bf16x8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
                 acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc_s[t4], 0, 0, 0);
             }
         }
@@ -163,14 +110,14 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, WAVE));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, WAVE));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(acc_s[t4][r] - m_new);
+                const float p = fast_exp2(acc_s[t4][r] - m_new);
                 acc_s[t4][r] = p;
                 psum += p;
             }
@@ -188,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
             for (int td = 0; td < 4; ++td) {
                 // hardware-transposed LDS read: lane i of the 16-lane group gets column d0+i of 4 key rows
                 const int k0 = 32 * u + 4 * g;
-                const unsigned char* a0 = tV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
+                const unsigned char* a0 = ldsV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
                 const unsigned char* a1 = a0 + 16 * 128;
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
@@ -198,6 +145,29 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
                 acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
             }
         }
+    }
+    if constexpr (KS == 2) {
+        // merge the two key groups' online-softmax states: group 1 -> LDS -> group 0
+        __syncthreads();
+        float* buf = reinterpret_cast<float*>(smem) + (wave * 64 + lane);   // [18][256] floats, lane-major
+        if (kgp == 1) {
+            buf[0 * 256] = m_run;
+            buf[1 * 256] = l_run;
+#pragma unroll
+            for (int td = 0; td < 4; ++td)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) buf[(2 + td * 4 + r) * 256] = acc_o[td][r];
+        }
+        __syncthreads();
+        if (kgp == 1) return;
+        const float m_b = buf[0 * 256], l_b = buf[1 * 256];
+        const float m_tot = fmaxf(m_run, m_b);
+        const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(m_b - m_tot);
+        l_run = l_run * wa + l_b * wb;
+#pragma unroll
+        for (int td = 0; td < 4; ++td)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + buf[(2 + td * 4 + r) * 256] * wb;
     }
     l_run += __shfl_xor(l_run, 16, WAVE);
     l_run += __shfl_xor(l_run, 32, WAVE);
@@ -214,14 +184,11 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16* __restr
 }
 
 // ------------------------------------------------------------------------------------ fp32
-template <bool RESIDENT>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int N, int D) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int ntiles_all = (N + 63) / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 256];
     unsigned char* ldsK = smem;
-    unsigned char* ldsV = smem + (RESIDENT ? ntiles_all : 1) * 64 * 256;
-    unsigned char* ldsQ = smem + 2 * ntiles_all * 64 * 256;   // RESIDENT only: 64 query rows x 256 B
+    unsigned char* ldsV = smem + 64 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = lane & 15, g = lane >> 4;
     const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -233,10 +200,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const int q = q0 + 16 * wave + qi;
     const int qrow = min(q, N - 1);
     float4 qf[4];
-    if constexpr (!RESIDENT) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + 16 * c + 4 * g);
-    }
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + 16 * c + 4 * g);
 
     f32x4 acc_o[4];
 #pragma unroll
@@ -253,60 +218,18 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)key * ld + schunk * 4);
         }
     };
-    const int ntiles = ntiles_all;
-    if constexpr (RESIDENT) {
-        typedef __attribute__((address_space(3))) void* lds_ptr;
-        typedef const __attribute__((address_space(1))) void* gbl_ptr;
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        // 16 KiB per 64-key tile per operand = 16 copy instructions of 1 KiB (4 keys x 256 B) each; every
-        // wave issues, tile by tile, 4 of the K and 4 of the V instructions (8 per tile).
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {   // Q through LDS: this wave's own 16 query rows (see the bf16 kernel)
-            const int r4 = wv * 4 + j;
-            const int row = r4 * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ (row & 15);
-            const float* srcp = base + (size_t)min(q0 + row, N - 1) * ld + c * 4;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)srcp, (lds_ptr)(ldsQ + r4 * 1024), 16, 0, 0);
-        }
-        for (int tt = 0; tt < ntiles; ++tt) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool isV = j >= 4;
-                const int r4 = tt * 16 + wv * 4 + (j & 3);          // group of 4 keys
-                const int row = (r4 & 15) * 4 + (lane >> 4);         // row inside its 64-key tile
-                const int key = min(tt * 64 + row, N - 1);
-                const int c = (lane & 15) ^ (row & 15);              // tile256_off swizzle, applied to the source
-                const float* srcp = (isV ? Vp : Kp) + (size_t)key * ld + c * 4;
-                unsigned char* dstp = (isV ? ldsV : ldsK) + r4 * 1024;
-                __builtin_amdgcn_global_load_lds((gbl_ptr)srcp, (lds_ptr)dstp, 16, 0, 0);
-            }
-        }
-    } else {
-        gload(0);
-    }
+    const int ntiles = (N + 63) / 64;
+    gload(0);
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
-        if constexpr (!RESIDENT) {
-            __syncthreads();
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<u32x4*>(ldsK + tile256_off(srow + 16 * i, schunk)) = rk[i];
-                *reinterpret_cast<u32x4*>(ldsV + tile256_off(srow + 16 * i, schunk)) = rv[i];
-            }
-            __syncthreads();
-            if (t + 1 < ntiles) gload(kb + 64);
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(ldsK + tile256_off(srow + 16 * i, schunk)) = rk[i];
+            *reinterpret_cast<u32x4*>(ldsV + tile256_off(srow + 16 * i, schunk)) = rv[i];
         }
-        if constexpr (RESIDENT) {
-            wait_copies<8>(ntiles - 1 - t);
-            __builtin_amdgcn_s_barrier();
-            if (t == 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    qf[c] = *reinterpret_cast<const float4*>(ldsQ + tile256_off(16 * wave + qi, 4 * c + g));
-            }
-        }
-        const unsigned char* tK = ldsK + (RESIDENT ? t * 64 * 256 : 0);
-        const unsigned char* tV = ldsV + (RESIDENT ? t * 64 * 256 : 0);
+        __syncthreads();
+        if (t + 1 < ntiles) gload(kb + 64);
 
         f32x4 acc_s[4];
 #pragma unroll
@@ -314,7 +237,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 kf = *reinterpret_cast<const float4*>(tK + tile256_off(16 * t4 + qi, 4 * c + g));
+                const float4 kf = *reinterpret_cast<const float4*>(ldsK + tile256_off(16 * t4 + qi, 4 * c + g));
                 acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, acc_s[t4], 0, 0, 0);
                 acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, acc_s[t4], 0, 0, 0);
                 acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, acc_s[t4], 0, 0, 0);
@@ -358,7 +281,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 const int key = 16 * t4 + 4 * g + r;
 #pragma unroll
                 for (int td = 0; td < 4; ++td) {
-                    const float v = *reinterpret_cast<const float*>(tV + tile256_off(key, 4 * td + (qi >> 2)) +
+                    const float v = *reinterpret_cast<const float*>(ldsV + tile256_off(key, 4 * td + (qi >> 2)) +
                                                                     (qi & 3) * 4);
                     acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, acc_s[t4][r], acc_o[td], 0, 0, 0);
                 }
@@ -376,44 +299,17 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
 }
 
-template <typename K>
-static int launch_attn(K kernel, dim3 grid, size_t lds, hipStream_t stream, const void* qkv, void* out, int N, int D,
-                       bool* raised) {
-    if (lds > 64 * 1024 && !*raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                144 * 1024) != hipSuccess)
-            return -1;
-        *raised = true;
-    }
-    return 0;
-}
-
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
     const int D = H * 64;
     const int nt = (N + 63) / 64;
-    dim3 grid(nt, H, n_img), block(256);
-    static bool raised_f32 = false, raised_bf16 = false;
-    // The resident (all K/V in LDS, counted waits) variant is kept for experiments: on MI355X it measured
-    // 1 % SLOWER end to end than streaming at N = 197 (A/B in one process, profiles/r01_notes.md), because the
-    // kernel is bound by the softmax VALU chain at one wave per SIMD, not by the K/V load latency.
-    static const bool force_stream = [] { const char* e = getenv("VITVS_ATTN_RESIDENT"); return !(e && e[0] == '1'); }();
+    dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
-        const size_t res = (size_t)(2 * nt + 1) * 64 * 256;
-        if (res <= 144 * 1024 && !force_stream) {
-            if (launch_attn(attention_f32_kernel<true>, grid, res, stream, qkv, out, N, D, &raised_f32)) return -1;
-            launch(attention_f32_kernel<true>, grid, block, res, stream, (const float*)qkv, (float*)out, N, D);
-        } else {
-            launch(attention_f32_kernel<false>, grid, block, 2 * 64 * 256, stream, (const float*)qkv, (float*)out, N, D);
-        }
+        launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
+    } else if ((long)nt * H * n_img <= 256 && nt >= 2 && !getenv("VITVS_ATTN_KS1")) {
+        launch(attention_bf16_kernel<2>, grid, dim3(512), 2 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else {
-        const size_t res = (size_t)(2 * nt + 1) * 64 * 128;
-        if (res <= 144 * 1024 && !force_stream) {
-            if (launch_attn(attention_bf16_kernel<true>, grid, res, stream, qkv, out, N, D, &raised_bf16)) return -1;
-            launch(attention_bf16_kernel<true>, grid, block, res, stream, (const bf16*)qkv, (bf16*)out, N, D);
-        } else {
-            launch(attention_bf16_kernel<false>, grid, block, 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
-        }
+        launch(attention_bf16_kernel<1>, grid, dim3(256), 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
