@@ -264,18 +264,28 @@ __global__ __launch_bounds__(256) void desc_plain_kernel(const float* __restrict
     }
     if (tok >= n_img * T) return;
     const int img = tok / T, t = tok - img * T;
-    const float* src = x + ((size_t)img * (T + 1) + 1 + t) * D;
+    const float4* src = reinterpret_cast<const float4*>(x + ((size_t)img * (T + 1) + 1 + t) * D);
+    // the row is read once, 16 bytes per lane (D <= 1024 -> at most 4 float4 per lane), and kept in registers
+    const int n4 = D >> 2;
+    float4 v[4];
     float s = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float v = src[d];
-        s += v * v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < n4) ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-8f);
-    float* dst = dn + (size_t)tok * D;
-    for (int d = lane; d < D; d += 64) {
-        const float v = src[d];
-        dst[d] = __fdiv_rn(v, nrm);
-        if (raw) raw[(size_t)tok * D + d] = v;
+    float4* dst = reinterpret_cast<float4*>(dn + (size_t)tok * D);
+    float4* rw = raw ? reinterpret_cast<float4*>(raw + (size_t)tok * D) : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 64 + lane;
+        if (c < n4) {
+            dst[c] = make_float4(__fdiv_rn(v[i].x, nrm), __fdiv_rn(v[i].y, nrm), __fdiv_rn(v[i].z, nrm),
+                                 __fdiv_rn(v[i].w, nrm));
+            if (rw) rw[c] = v[i];
+        }
     }
 }
 

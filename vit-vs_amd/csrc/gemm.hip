@@ -4,6 +4,8 @@
 //   fc1 -> GELU -> fc2     dino_patch/block.py:78-84 (Mlp, nn.GELU = erf form)
 //   residual + LayerScale  dino_patch/block.py:90-96, 112-115
 //   patch-embed Conv2d     dinov2_extractor.py:141, 259 (k = p, stride) as an im2col GEMM
+#include <stdlib.h>
+
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -173,7 +175,16 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& 
                         int splits = 1, bool fixed64 = false) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
-    const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
+    TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
+    if (const char* e = getenv("VITVS_TILE_BN")) {   // experiment switch: force the column-tile width
+        const int bn = atoi(e);
+        if ((bn == 64 || bn == 96 || bn == 128) && N % bn == 0) {
+            pl.bn = bn;
+            const long wgs = (long)((M + 63) / 64) * (N / bn);
+            pl.kg = (wgs <= 256 && (K / bk) >= 4 && (K / bk) % 2 == 0) ? 2 : 1;
+            if (getenv("VITVS_TILE_KG2") && (K / bk) % 2 == 0) pl.kg = 2;
+        }
+    }
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
         return launch_one<T, 128, 1, Epi>(A, W, M, N, K, epi, stream, splits);

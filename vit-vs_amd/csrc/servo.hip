@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
     int* sel = flag + T;            // [max_rows]
     int* scratch = sel + a.max_rows;  // [8 + 256]
     float* fscr = reinterpret_cast<float*>(scratch + 8 + 256);  // [4]
-    double* Llds = reinterpret_cast<double*>(smem + (((size_t)(3 * T + a.max_rows + 8 + 256 + 4) * 4 + 15) & ~(size_t)15));
+    float* simL = fscr + 4;                                     // [T] sim_1, kept on chip for the feature stage
+    double* Llds = reinterpret_cast<double*>(smem + (((size_t)(4 * T + a.max_rows + 8 + 256 + 4) * 4 + 15) & ~(size_t)15));
+    // camera intrinsics: issued now, needed only in the feature stage (one memory round trip hidden)
+    const double fx = a.K[b * 4 + 0], fy = a.K[b * 4 + 1], cx = a.K[b * 4 + 2], cy = a.K[b * 4 + 3];
 
     const unsigned long long* rb = a.row_best + (size_t)b * T;
     const unsigned long long* cb = a.col_best + (size_t)b * T;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
         a.nn1[(size_t)b * T + i] = n1;
         a.nn2[(size_t)b * T + i] = n2;
         a.sim1[(size_t)b * T + i] = s1;
+        simL[i] = s1;
         ssum += s1;
     }
     ssum = wave_sum(ssum);
@@ -144,7 +148,6 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
     const bool use_lds = R <= kLdsRows;
     const int rcap = use_lds ? kLdsRows : 2 * a.max_rows;
     double* Lc = use_lds ? Llds : a.L_ws + (size_t)b * 7 * 2 * a.max_rows;   // 6 columns + e, column-major
-    const double fx = a.K[b * 4 + 0], fy = a.K[b * 4 + 1], cx = a.K[b * 4 + 2], cy = a.K[b * 4 + 3];
     const uint16_t* depth = a.depth ? a.depth + (size_t)b * a.depth_h * a.depth_w : nullptr;
     int32_t* uv_out = a.s_uv + (size_t)b * a.max_rows * 4;
     double* feat_out = a.feat + (size_t)b * a.max_rows * 4;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
             vs = (long)rint((double)r1 * a.scale_y);
             u = (long)rint((double)c2 * a.scale_x);
             v = (long)rint((double)r2 * a.scale_y);
-            simk = same_image ? 1.0 : (double)a.sim1[(size_t)b * T + tok];
+            simk = same_image ? 1.0 : (double)simL[tok];
         }
         const double x = ((double)u - cx) / fx, y = ((double)v - cy) / fy;
         const double xs = ((double)us - cx) / fx, ys = ((double)vs - cy) / fy;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
     // 5. v_c = -lambda * pinv(L) e, fp64.
     // Fast path (L_e of full column rank and well conditioned, the normal servo case): pinv(L) e is the
     // least-squares solution, obtained from the 6x6 normal equations by Cholesky; 27 threads form
-    // G = L^T L and g = L^T e, one thread factors and solves.  If a pivot falls below 1e-8 of its
+    // G = L^T L and g = L^T e, one thread factors (LDL^T) and solves.  If a pivot falls below 1e-8 of its
     // diagonal (cond(L) > ~1e4, or rank deficiency, e.g. all-identical zero-padded rows) the general
     // path below runs instead: one-sided Jacobi SVD with numpy.linalg.pinv's rcond = 1e-15 cut-off.
     int status = ST_OK;
@@ -207,19 +210,30 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
     double* Gs = Llds + 7 * kLdsRows;   // [27] G (21, upper triangle row-major) + g (6); [27..33] solution, [34] flag
     bool solved = false;
     if (status == ST_OK && R > 0 && use_lds) {
-        if (tid < 27) {
-            int ca, cb;
-            if (tid < 21) {
-                int q = tid;
-                ca = 0;
-                while (q >= 6 - ca) { q -= 6 - ca; ++ca; }
-                cb = ca + q;
-            } else {
-                ca = tid - 21;
-                cb = 6;
+        // 27 quantities x 8 row slices on 216 threads (fixed slice order -> deterministic), then 27 sums of 8
+        {
+            const int qid = tid & 31, slice = tid >> 5;
+            if (qid < 27) {
+                int ca, cb;
+                if (qid < 21) {
+                    int q = qid;
+                    ca = 0;
+                    while (q >= 6 - ca) { q -= 6 - ca; ++ca; }
+                    cb = ca + q;
+                } else {
+                    ca = qid - 21;
+                    cb = 6;
+                }
+                double acc = 0.0;
+                for (int r = slice; r < R; r += 8) acc += Lc[ca * rcap + r] * Lc[cb * rcap + r];
+                Gs[40 + slice * 27 + qid] = acc;
             }
+        }
+        __syncthreads();
+        if (tid < 27) {
             double acc = 0.0;
-            for (int r = 0; r < R; ++r) acc += Lc[ca * rcap + r] * Lc[cb * rcap + r];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) acc += Gs[40 + sl * 27 + tid];
             Gs[tid] = acc;
         }
         __syncthreads();
@@ -229,31 +243,32 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
             for (int i = 0; i < 6; ++i)
                 for (int j = i; j < 6; ++j) { Gm[i][j] = Gs[q]; Gm[j][i] = Gs[q]; ++q; }
             for (int i = 0; i < 6; ++i) rhs[i] = Gs[21 + i];
+            // G = L D L^T (unit lower-triangular L, no square roots, one reciprocal per pivot)
             bool good = true;
-            double Lf[6][6];
+            double Lf[6][6], dinv[6], dpiv[6];
             for (int j = 0; j < 6 && good; ++j) {
                 double d = Gm[j][j];
-                for (int k = 0; k < j; ++k) d -= Lf[j][k] * Lf[j][k];
+                for (int k = 0; k < j; ++k) d -= Lf[j][k] * Lf[j][k] * dpiv[k];
                 if (!(d > 1e-8 * Gm[j][j]) || !(Gm[j][j] > 0.0)) { good = false; break; }
-                const double dj = sqrt(d);
-                Lf[j][j] = dj;
+                dpiv[j] = d;
+                dinv[j] = 1.0 / d;
                 for (int i = j + 1; i < 6; ++i) {
                     double t = Gm[i][j];
-                    for (int k = 0; k < j; ++k) t -= Lf[i][k] * Lf[j][k];
-                    Lf[i][j] = t / dj;
+                    for (int k = 0; k < j; ++k) t -= Lf[i][k] * Lf[j][k] * dpiv[k];
+                    Lf[i][j] = t * dinv[j];
                 }
             }
             if (good) {
                 double y[6], xsol[6];
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 6; ++i) {          // L y = rhs
                     double t = rhs[i];
                     for (int k = 0; k < i; ++k) t -= Lf[i][k] * y[k];
-                    y[i] = t / Lf[i][i];
+                    y[i] = t;
                 }
-                for (int i = 5; i >= 0; --i) {
-                    double t = y[i];
+                for (int i = 5; i >= 0; --i) {         // L^T x = D^-1 y
+                    double t = y[i] * dinv[i];
                     for (int k = i + 1; k < 6; ++k) t -= Lf[k][i] * xsol[k];
-                    xsol[i] = t / Lf[i][i];
+                    xsol[i] = t;
                 }
                 for (int i = 0; i < 6; ++i) Gs[27 + i] = -a.lambda * xsol[i];
             }
@@ -347,8 +362,8 @@ __global__ __launch_bounds__(256) void servo_kernel(ServoArgs a) {
 int launch_servo(const ServoArgs& a, hipStream_t stream) {
     if (a.n_pairs <= 0 || a.T <= 0 || a.grid * a.grid != a.T || a.max_rows < a.num_pairs || a.num_pairs <= 0) return -2;
     if (a.mode == SEL_DENSE && a.max_rows < a.T) return -2;
-    size_t ints = (size_t)3 * a.T + a.max_rows + 8 + 256 + 4;
-    size_t lds = ((ints * 4 + 15) & ~(size_t)15) + (size_t)7 * kLdsRows * 8 + 40 * 8;
+    size_t ints = (size_t)4 * a.T + a.max_rows + 8 + 256 + 4;
+    size_t lds = ((ints * 4 + 15) & ~(size_t)15) + (size_t)7 * kLdsRows * 8 + (40 + 8 * 27) * 8;
     if (lds > 64 * 1024) return -3;
     launch(servo_kernel, dim3(a.n_pairs), dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
