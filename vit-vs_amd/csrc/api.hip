@@ -250,6 +250,83 @@ struct Span {
     }
 };
 
+// One launch chain's view of the workspaces (a contiguous range of images).
+struct ChainCtx {
+    int cnt = 0, M = 0;
+    float* x = nullptr;
+    unsigned char *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr, *Ape = nullptr;
+    float* part = nullptr;
+    PatchifyArgs pa;
+};
+
+// The default (split-K + residual_ln) forward, operator by operator, for n chains on one stream (n = 1 in
+// production).  n = 2 with the second chain's launches flagged hipExtAnyOrderLaunch (no AQL barrier bit) was
+// tried to overlap the two frames inside one queue: gfx9 ignores the flag (hip_ext.h says so, and the update
+// took 0.90 ms instead of 0.53 ms), so kernels of one update cannot overlap on this platform.
+int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
+    const vitvs_config& c = h->cfg;
+    const int D = c.dim;
+    int rc = 0;
+    for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCHIFY, st);
+        rc = launch_patchify(h->prec, cx[k].pa, cx[k].Ape, cx[k].x, st); }
+    for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCH_EMBED, st);
+        rc = launch_patch_embed(h->prec, cx[k].Ape, h->pe_w, h->pe_b, h->pos, cx[k].x, cx[k].cnt, h->T, D, h->Kp, st); }
+    // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
+    // fc2 (split-K partials) -> [residual + norm1 of block i+1].  Only block 0's norm1 is a launch of its own.
+    for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_LAYERNORM, st);
+        rc = launch_layernorm(h->prec, cx[k].x, h->blk[0].n1w, h->blk[0].n1b, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
+    for (int i = 0; i < c.blocks && !rc; ++i) {
+        const Block& b = h->blk[i];
+        const Block* nx = (i + 1 < c.blocks) ? &h->blk[i + 1] : nullptr;
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_QKV, st);
+            rc = launch_linear(h->prec, cx[k].xn, b.qkvw, b.qkvb, cx[k].qkv, cx[k].M, 3 * D, D, 0, st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_ATTENTION, st);
+            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PROJ, st);
+            rc = launch_linear_partial(h->prec, cx[k].attn, b.projw, cx[k].part, cx[k].M, D, D,
+                                       splitk_slices(h->prec, cx[k].M, D, D), st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_RESIDUAL_LN, st);
+            rc = launch_residual_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].M, D, D), b.projb, b.ls1,
+                                    b.n2w, b.n2b, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_FC1, st);
+            rc = launch_linear(h->prec, cx[k].xn, b.fc1w, b.fc1b, cx[k].hid, cx[k].M, h->hidden, D, 1, st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_FC2, st);
+            rc = launch_linear_partial(h->prec, cx[k].hid, b.fc2w, cx[k].part, cx[k].M, D, h->hidden,
+                                       splitk_slices(h->prec, cx[k].M, D, h->hidden), st); }
+        for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_RESIDUAL_LN, st);
+            rc = launch_residual_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].M, D, h->hidden), b.fc2b,
+                                    b.ls2, nx ? nx->n1w : nullptr, nx ? nx->n1b : nullptr, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
+    }
+    if (rc) return set_err(h, rc, "forward launch failed");
+    return 0;
+}
+
+ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part) {
+    const vitvs_config& c = h->cfg;
+    const int D = c.dim;
+    const size_t es = elem_size(h->prec);
+    const size_t img_bytes = (size_t)c.img_size * c.img_size * 3;
+    const size_t row0 = (size_t)i0 * h->N;
+    ChainCtx cx;
+    cx.cnt = cnt; cx.M = cnt * h->N; cx.part = part;
+    cx.x = h->x + row0 * D;
+    cx.xn = (unsigned char*)h->xn + row0 * D * es;
+    cx.qkv = (unsigned char*)h->qkv + row0 * 3 * D * es;
+    cx.attn = (unsigned char*)h->attn + row0 * D * es;
+    cx.hid = (unsigned char*)h->hid + row0 * h->hidden * es;
+    cx.Ape = (unsigned char*)h->Ape + (size_t)i0 * h->T * h->Kp * es;
+    PatchifyArgs& pa = cx.pa;
+    pa.n_des = std::max(0, std::min(i0 + cnt, n_des) - i0);
+    pa.n_cur = cnt - pa.n_des;
+    pa.des = des ? des + (size_t)std::min(i0, n_des) * img_bytes : nullptr;
+    pa.cur = cur ? cur + (size_t)std::max(i0 - n_des, 0) * img_bytes : nullptr;
+    pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
+    for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
+    pa.cls = h->cls; pa.pos = h->pos;
+    pa.xb = nullptr; pa.stats = nullptr;
+    return cx;
+}
+
 // Forward of images [i0, i0 + cnt) of the call's image list (desired frames first, then current
 // frames) on stream `st`: an independent chain of launches touching only those images' rows.
 int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part,
@@ -302,33 +379,10 @@ int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
         }
         return 0;
     }
-    { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, Ape, x, st); }
-    if (rc) return set_err(h, rc, "patchify launch failed");
-    { Span sp(h, KC_PATCH_EMBED, st);
-      rc = launch_patch_embed(h->prec, Ape, h->pe_w, h->pe_b, h->pos, x, cnt, h->T, D, h->Kp, st); }
-    if (rc) return set_err(h, rc, "patch-embed launch failed");
-    // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
-    // fc2 (split-K partials) -> [residual + norm1 of block i+1].  Only block 0's norm1 is a launch of its own.
-    { Span sp(h, KC_LAYERNORM, st);
-      rc = launch_layernorm(h->prec, x, h->blk[0].n1w, h->blk[0].n1b, xn, M, D, c.ln_eps, st); }
-    if (rc) return set_err(h, rc, "layernorm launch failed");
-    const int s_proj = splitk_slices(h->prec, M, D, D), s_fc2 = splitk_slices(h->prec, M, D, h->hidden);
-    for (int i = 0; i < c.blocks; ++i) {
-        const Block& b = h->blk[i];
-        const Block* nx = (i + 1 < c.blocks) ? &h->blk[i + 1] : nullptr;
-        { Span sp(h, KC_QKV, st); rc = launch_linear(h->prec, xn, b.qkvw, b.qkvb, qkv, M, 3 * D, D, 0, st); }
-        if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, qkv, attn, cnt, h->N, c.heads, st); }
-        if (!rc) { Span sp(h, KC_PROJ, st); rc = launch_linear_partial(h->prec, attn, b.projw, part, M, D, D, s_proj, st); }
-        if (!rc) { Span sp(h, KC_RESIDUAL_LN, st);
-                   rc = launch_residual_ln(h->prec, x, part, s_proj, b.projb, b.ls1, b.n2w, b.n2b, xn, M, D, c.ln_eps, st); }
-        if (!rc) { Span sp(h, KC_FC1, st); rc = launch_linear(h->prec, xn, b.fc1w, b.fc1b, hid, M, h->hidden, D, 1, st); }
-        if (!rc) { Span sp(h, KC_FC2, st); rc = launch_linear_partial(h->prec, hid, b.fc2w, part, M, D, h->hidden, s_fc2, st); }
-        if (!rc) { Span sp(h, KC_RESIDUAL_LN, st);
-                   rc = launch_residual_ln(h->prec, x, part, s_fc2, b.fc2b, b.ls2, nx ? nx->n1w : nullptr,
-                                           nx ? nx->n1b : nullptr, xn, M, D, c.ln_eps, st); }
-        if (rc) return set_err(h, rc, "block launch failed");
-    }
-    return 0;
+    ChainCtx cx;
+    cx.cnt = cnt; cx.M = M; cx.x = x; cx.xn = xn; cx.qkv = qkv; cx.attn = attn; cx.hid = hid; cx.Ape = Ape; cx.part = part;
+    cx.pa = pa;
+    return forward_lockstep(h, &cx, 1, st);
 }
 
 // The images of one call are independent until the correspondence stage, and at one frame pair each
