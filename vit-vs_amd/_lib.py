@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitvs_hip.so")
+# VITVS_LIB points at another build of the same sources (A/B experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("VITVS_LIB") or os.path.join(_HERE, "libvitvs_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 1

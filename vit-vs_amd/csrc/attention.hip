@@ -11,11 +11,12 @@
 // its query on the lane, so the running rescale is a per-lane multiply.  The MFMA k-slot -> key map
 // is permuted the same way for P and V (any bijection is legal as long as both operands agree).
 //
-// bf16 kernel, KS = 2 ("key split"): at one frame pair there are only 96 workgroups of 4 key tiles, and
-// the tile loop is a serial chain (MFMA -> softmax VALU -> MFMA) at one wave per SIMD.  With KS = 2 a
-// workgroup has 8 waves: waves 0-3 take the first half of the key tiles, waves 4-7 the second half
-// (own LDS stage each), and the two partial (max, sum, O) states are merged through LDS at the end —
-// half the chain length, two waves per SIMD.  Long sequences (many workgroups) use KS = 1.
+// bf16 kernel, KS = 2 / 4 ("key split"): at one frame pair there are only 96 workgroups of 4 key tiles, and
+// the tile loop is a serial chain (MFMA -> softmax VALU -> MFMA) at one wave per SIMD.  With KS key groups a
+// workgroup has 4 KS waves: group k takes the k-th share of the key tiles (own LDS stage each), and the
+// partial (max, sum, O) states are merged through LDS at the end in a fixed order — 1/KS of the chain
+// length, KS waves per SIMD.  Long sequences (many workgroups) use KS = 1.  KS = 2 is what is launched:
+// KS = 4 (16 waves, one key tile per group at 197 tokens) was measured 1 % slower end to end.
 // (A variant that kept all K/V of a head resident in LDS, filled by LDS-DMA with counted waits, was
 // measured 1 % slower end to end than this streaming form and was removed: profiles/r01_notes.md.)
 #include <stdlib.h>
@@ -146,28 +147,34 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
             }
         }
     }
-    if constexpr (KS == 2) {
-        // merge the two key groups' online-softmax states: group 1 -> LDS -> group 0
+    if constexpr (KS >= 2) {
+        // merge the key groups' online-softmax states: groups 1 .. KS-1 -> LDS -> group 0 (fixed order)
         __syncthreads();
-        float* buf = reinterpret_cast<float*>(smem) + (wave * 64 + lane);   // [18][256] floats, lane-major
-        if (kgp == 1) {
-            buf[0 * 256] = m_run;
-            buf[1 * 256] = l_run;
+        float* buf = reinterpret_cast<float*>(smem) + (wave * 64 + lane);   // [KS-1][18][256] floats, lane-major
+        if (kgp >= 1) {
+            float* mine = buf + (kgp - 1) * 18 * 256;
+            mine[0 * 256] = m_run;
+            mine[1 * 256] = l_run;
 #pragma unroll
             for (int td = 0; td < 4; ++td)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) buf[(2 + td * 4 + r) * 256] = acc_o[td][r];
+                for (int r = 0; r < 4; ++r) mine[(2 + td * 4 + r) * 256] = acc_o[td][r];
         }
         __syncthreads();
-        if (kgp == 1) return;
-        const float m_b = buf[0 * 256], l_b = buf[1 * 256];
-        const float m_tot = fmaxf(m_run, m_b);
-        const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(m_b - m_tot);
-        l_run = l_run * wa + l_b * wb;
+        if (kgp >= 1) return;
 #pragma unroll
-        for (int td = 0; td < 4; ++td)
+        for (int o = 0; o < KS - 1; ++o) {
+            const float* other = buf + o * 18 * 256;
+            const float m_b = other[0 * 256], l_b = other[1 * 256];
+            const float m_tot = fmaxf(m_run, m_b);
+            const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(m_b - m_tot);
+            m_run = m_tot;
+            l_run = l_run * wa + l_b * wb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + buf[(2 + td * 4 + r) * 256] * wb;
+            for (int td = 0; td < 4; ++td)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + other[(2 + td * 4 + r) * 256] * wb;
+        }
     }
     l_run += __shfl_xor(l_run, 16, WAVE);
     l_run += __shfl_xor(l_run, 32, WAVE);
@@ -306,7 +313,7 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
-    } else if ((long)nt * H * n_img <= 256 && nt >= 2 && !getenv("VITVS_ATTN_KS1")) {
+    } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch(attention_bf16_kernel<2>, grid, dim3(512), 2 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else {
         launch(attention_bf16_kernel<1>, grid, dim3(256), 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);

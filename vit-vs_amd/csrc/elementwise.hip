@@ -152,10 +152,11 @@ constexpr int SMAX = 8;  // most K slices splitk_slices() ever picks
 
 template <typename T, int NV4, int LANES>
 __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, const float* __restrict__ part,
-                                                         int splits, const float* __restrict__ bias,
-                                                         const float* __restrict__ ls, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, T* __restrict__ out, int M,
-                                                         float eps) {
+                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ out, int splits,
+                                                         int M, const float* __restrict__ ls, float eps) {
+    // argument order: the first 14 dwords are preloaded into SGPRs (kernarg preload); `ls` and `eps` are
+    // fetched by the wave and first used after every other load is in flight
     constexpr int D = 4 * NV4 * LANES;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x;
@@ -164,23 +165,26 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
     float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
     float4 v[NV4], pv[SMAX][NV4], bb[NV4], ll[NV4], gg[NV4], be[NV4];
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-        const int c = i * LANES + l;
-        v[i] = xr[c];
-        bb[i] = reinterpret_cast<const float4*>(bias)[c];
-        if (ls) ll[i] = reinterpret_cast<const float4*>(ls)[c];
-        if (gamma) {
-            gg[i] = reinterpret_cast<const float4*>(gamma)[c];
-            be[i] = reinterpret_cast<const float4*>(beta)[c];
-        }
-    }
-#pragma unroll
     for (int z = 0; z < SMAX; ++z)
         if (z < splits) {
             const float4* pz = reinterpret_cast<const float4*>(part + ((size_t)z * M + row) * D);
 #pragma unroll
             for (int i = 0; i < NV4; ++i) pv[z][i] = pz[i * LANES + l];
         }
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = i * LANES + l;
+        v[i] = xr[c];
+        bb[i] = reinterpret_cast<const float4*>(bias)[c];
+        if (gamma) {
+            gg[i] = reinterpret_cast<const float4*>(gamma)[c];
+            be[i] = reinterpret_cast<const float4*>(beta)[c];
+        }
+    }
+    if (ls) {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) ll[i] = reinterpret_cast<const float4*>(ls)[i * LANES + l];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
@@ -230,7 +234,7 @@ static int launch_rln_t(float* x, const float* part, int splits, const float* bi
                         const float* b, T* out, int M, int D, float eps, hipStream_t stream) {
     dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
 #define VITVS_RLN(NV4, LANES) \
-    launch((residual_ln_kernel<T, NV4, LANES>), grid, block, 0, stream, x, part, splits, bias, ls, g, b, out, M, eps)
+    launch((residual_ln_kernel<T, NV4, LANES>), grid, block, 0, stream, x, part, bias, g, b, out, splits, M, ls, eps)
     switch (D) {
         case 128: VITVS_RLN(1, 32); break;
         case 256: VITVS_RLN(1, 64); break;

@@ -34,14 +34,20 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
     return 0.5f * v * (1.0f + copysignf(e, v));
 }
 
+// Every epilogue is built inside the kernel from the same flat argument list (out, c0, c1, M, N, i0):
+// flat leading kernel arguments are preloaded into SGPRs by the command processor
+// (-amdgpu-kernarg-preload-count), a by-value struct would be fetched by the wave after it starts.
 template <typename T>
 struct EpiStore {
     T* out;
     const float* bias;
     int ldo;
     int gelu;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    __device__ __forceinline__ static EpiStore make(void* out, const float* c0, const float*, int, int N, int i0) {
+        return EpiStore{(T*)out, c0, N, i0};
+    }
+    __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
 #pragma unroll
@@ -56,8 +62,11 @@ struct EpiResidual {
     const float* bias;
     const float* ls;  // may be null
     int ld;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    __device__ __forceinline__ static EpiResidual make(void* out, const float* c0, const float* c1, int, int N, int) {
+        return EpiResidual{(float*)out, c0, c1, N};
+    }
+    __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (ls) {
             const float4 g = *reinterpret_cast<const float4*>(ls + n);
@@ -75,9 +84,12 @@ struct EpiPatch {
     const float* bias;
     const float* pos;
     int T, D;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    __device__ __forceinline__ static EpiPatch make(void* out, const float* c0, const float* c1, int, int N, int i0) {
+        return EpiPatch{(float*)out, c0, c1, i0, N};
+    }
+    __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
         const int img = m / T, t = m - img * T;
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
         const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n);
         float4 r = make_float4(v[0] + b.x + pe.x, v[1] + b.y + pe.y, v[2] + b.z + pe.z, v[3] + b.w + pe.w);
         *reinterpret_cast<float4*>(x + ((size_t)img * (T + 1) + 1 + t) * D + n) = r;
@@ -90,23 +102,37 @@ struct EpiPatch {
 struct EpiPartial {
     float* part;
     int M, N;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    __device__ __forceinline__ static EpiPartial make(void* out, const float*, const float*, int M, int N, int) {
+        return EpiPartial{(float*)out, M, N};
+    }
+    __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4) const {
         *reinterpret_cast<float4*>(part + ((size_t)blockIdx.z * M + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
 
 template <typename T, int BM, int BN, int KG, class Epi>
-__global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, int M,
-                                                          int N, int K, Epi epi) {
+__global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
+                                                          const float* c0, const float* c1, int M, int N, int K,
+                                                          int i0) {
     using Tile = GemmTile<BM, BN, KG>;
+    const Epi epi = Epi::make(out, c0, c1, M, N, i0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
-    const int kslice = K / gridDim.z;
-    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;
     const int kg = (KG == 2) ? k_group() : 0;
+    // per-column epilogue terms (bias) are requested BEFORE the main loop: they are older than every tile
+    // copy, so the counted waits are unaffected, and their memory round trip is off the epilogue's path
+    float4 col[Tile::NT];
+#pragma unroll
+    for (int ni = 0; ni < Tile::NT; ++ni) {
+        const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
+        if (!(KG == 2 && tile_owner<Tile::NT>(ni) != kg)) col[ni] = epi.column_terms(min(n, N - 4));
+    }
+    const int kslice = K / gridDim.z;
+    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
         if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
-            if (m < M && n < N) epi(m, n, acc[ni][mi]);
+            if (m < M && n < N) epi(m, n, acc[ni][mi], col[ni]);
         }
     }
 }
@@ -150,8 +176,15 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
     return TilePlan{bn, kg};
 }
 
+struct EpiArgs {   // host image of the flat epilogue arguments
+    void* out;
+    const float* c0;
+    const float* c1;
+    int i0;
+};
+
 template <typename T, int BN, int KG, class Epi, int BM = 64>
-static int launch_one(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream, int splits) {
+static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs& e, hipStream_t stream, int splits) {
     using Tile = GemmTile<BM, BN, KG>;
     static bool raised = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
     if (!raised) {
@@ -161,7 +194,8 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const Epi& ep
         raised = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
-    launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, M, N, K, epi);
+    launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1, M,
+           N, K, e.i0);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -171,7 +205,7 @@ static bool big_problem(int M, int N, int splits) {
 }
 
 template <typename T, class Epi>
-static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
+static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiArgs& epi, hipStream_t stream,
                         int splits = 1, bool fixed64 = false) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
@@ -199,7 +233,7 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const Epi& 
 
 // narrow layers / patch embed: 64-wide tiles only (keeps the number of instantiations down)
 template <typename T, class Epi>
-static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi& epi, hipStream_t stream,
+static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const EpiArgs& epi, hipStream_t stream,
                           int splits = 1) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
@@ -211,20 +245,17 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    if (p == PREC_F32) {
-        EpiStore<float> e{(float*)out, bias, N, gelu};
-        return launch_tiles<float>((const float*)A, (const float*)W, M, N, K, e, stream);
-    }
-    EpiStore<bf16> e{(bf16*)out, bias, N, gelu};
-    return launch_tiles<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+    const EpiArgs e{out, bias, nullptr, gelu};
+    if (p == PREC_F32) return launch_tiles<float, EpiStore<float>>((const float*)A, (const float*)W, M, N, K, e, stream);
+    return launch_tiles<bf16, EpiStore<bf16>>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
                            int M, int N, int K, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    EpiResidual e{x, bias, ls, N};
-    if (p == PREC_F32) return launch_tiles64<float>((const float*)A, (const float*)W, M, N, K, e, stream);
-    return launch_tiles64<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
+    const EpiArgs e{x, bias, ls, 0};
+    if (p == PREC_F32) return launch_tiles64<float, EpiResidual>((const float*)A, (const float*)W, M, N, K, e, stream);
+    return launch_tiles64<bf16, EpiResidual>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
 int splitk_slices(Precision p, int M, int N, int K) {
@@ -243,18 +274,18 @@ int splitk_slices(Precision p, int M, int N, int K) {
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
                           hipStream_t stream) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
-    EpiPartial e{part, M, N};
-    if (p == PREC_F32) return launch_tiles64<float>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
-    return launch_tiles64<bf16>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
+    const EpiArgs e{part, nullptr, nullptr, 0};
+    if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
+    return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
                        int n_img, int T, int D, int Kp, hipStream_t stream) {
     const int M = n_img * T;
     if (!shapes_ok(p, M, D, Kp)) return -2;
-    EpiPatch e{x, bias, pos, T, D};
-    if (p == PREC_F32) return launch_tiles64<float>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
-    return launch_tiles64<bf16>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
+    const EpiArgs e{x, bias, pos, T};
+    if (p == PREC_F32) return launch_tiles64<float, EpiPatch>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
+    return launch_tiles64<bf16, EpiPatch>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
 }
 
 }  // namespace vitvs

@@ -46,7 +46,9 @@ struct GemmTile {
     static constexpr int MT = WM / 16, NT = WN / 16;    // 16x16 MFMA tiles per wave
     static constexpr int ROWS = BM + BN;
     static constexpr int L = ROWS / 32;                 // LDS-DMA instructions per wave per k-tile
-    static constexpr int NST = (KG == 1) ? 4 : 3;       // ring stages per k-group
+    // ring stages per k-group.  (A 4-stage ring for the two-k-group tiles that fit the 160 KB of LDS
+    // was measured 0.7 % SLOWER end to end at one frame pair: profiles/r01_notes.md.)
+    static constexpr int NST = (KG == 1) ? 4 : 3;
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
     static constexpr int LDS_BYTES = KG * GROUP_BYTES;
