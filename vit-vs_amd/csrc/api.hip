@@ -61,6 +61,7 @@ struct vitvs_handle {
     std::map<std::string, bool> have;
     std::map<std::string, std::vector<float>> stash;   // host copies of the tensors the LayerNorm folding needs
     bool fused_ln = true, folded = false;
+    int desc_keys = -1;   // >= 0 while a velocity update runs: the forward's last launch emits the descriptors and clears this many keys
     bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
     void* xb = nullptr;       // residual stream in the GEMM operand type (bf16 mode), [M][D]
     float* stats = nullptr;   // per-row partial moments [M][D/16][2]
@@ -251,12 +252,17 @@ struct Span {
 };
 
 // One launch chain's view of the workspaces (a contiguous range of images).
+// Plain descriptors of the default forward are produced by the forward's own last launch.
+static bool desc_in_forward(const vitvs_handle* h) { return !h->cfg.binned && !h->fused_ln && h->Dp == h->cfg.dim; }
+
 struct ChainCtx {
     int cnt = 0, M = 0;
     float* x = nullptr;
     unsigned char *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr, *Ape = nullptr;
     float* part = nullptr;
     PatchifyArgs pa;
+    bool want_desc = false;   // the last residual_ln also writes the plain descriptors (launch_residual_ln)
+    DescOut desc;
 };
 
 // The default (split-K + residual_ln) forward, operator by operator, for n chains on one stream (n = 1 in
@@ -269,12 +275,16 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     int rc = 0;
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCHIFY, st);
         rc = launch_patchify(h->prec, cx[k].pa, cx[k].Ape, cx[k].x, st); }
-    for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCH_EMBED, st);
-        rc = launch_patch_embed(h->prec, cx[k].Ape, h->pe_w, h->pe_b, h->pos, cx[k].x, cx[k].cnt, h->T, D, h->Kp, st); }
+    // Patch embedding as a split-K GEMM (more workgroups than its 84 output tiles), finished together with
+    // cls / pos_embed and block 0's norm1 by one residual_ln-style launch.
     // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
-    // fc2 (split-K partials) -> [residual + norm1 of block i+1].  Only block 0's norm1 is a launch of its own.
+    // fc2 (split-K partials) -> [residual + norm1 of block i+1].
+    for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCH_EMBED, st);
+        rc = launch_linear_partial(h->prec, cx[k].Ape, h->pe_w, cx[k].part, cx[k].cnt * h->T, D, h->Kp,
+                                   splitk_slices(h->prec, cx[k].cnt * h->T, D, h->Kp), st); }
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_LAYERNORM, st);
-        rc = launch_layernorm(h->prec, cx[k].x, h->blk[0].n1w, h->blk[0].n1b, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
+        rc = launch_embed_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].cnt * h->T, D, h->Kp), h->pe_b, h->pos,
+                             h->cls, h->blk[0].n1w, h->blk[0].n1b, cx[k].xn, cx[k].cnt, h->T, D, c.ln_eps, st); }
     for (int i = 0; i < c.blocks && !rc; ++i) {
         const Block& b = h->blk[i];
         const Block* nx = (i + 1 < c.blocks) ? &h->blk[i + 1] : nullptr;
@@ -295,7 +305,8 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
                                        splitk_slices(h->prec, cx[k].M, D, h->hidden), st); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_RESIDUAL_LN, st);
             rc = launch_residual_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].M, D, h->hidden), b.fc2b,
-                                    b.ls2, nx ? nx->n1w : nullptr, nx ? nx->n1b : nullptr, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
+                                    b.ls2, nx ? nx->n1w : nullptr, nx ? nx->n1b : nullptr, cx[k].xn, cx[k].M, D, c.ln_eps, st,
+                                    (!nx && cx[k].want_desc) ? &cx[k].desc : nullptr); }
     }
     if (rc) return set_err(h, rc, "forward launch failed");
     return 0;
@@ -382,6 +393,13 @@ int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     ChainCtx cx;
     cx.cnt = cnt; cx.M = M; cx.x = x; cx.xn = xn; cx.qkv = qkv; cx.attn = attn; cx.hid = hid; cx.Ape = Ape; cx.part = part;
     cx.pa = pa;
+    if (h->desc_keys >= 0 && desc_in_forward(h)) {
+        cx.want_desc = true;
+        cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
+        cx.desc.zero_a = h->row_best; cx.desc.zero_b = h->col_best;
+        cx.desc.T = h->T;
+        cx.desc.zero_count = (i0 == 0) ? h->desc_keys : 0;
+    }
     return forward_lockstep(h, &cx, 1, st);
 }
 
@@ -725,18 +743,23 @@ static int segment_forward(vitvs_handle* h, const UpdateArgs& u, int which, hipS
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
     const int first = h->two_chains ? n_img / 2 : n_img;
     const size_t part_half = (size_t)8 * (h->n_img_max / 2 + 1) * h->N * h->cfg.dim;
-    if (which == 0) return forward_chain(h, 0, first, n_des, u.I_des, u.I_cur, h->part, st);
-    if (first == n_img) return 0;
-    return forward_chain(h, first, n_img - first, n_des, u.I_des, u.I_cur, h->part + part_half, st);
+    h->desc_keys = u.n_pairs * h->T;
+    int rc = 0;
+    if (which == 0) rc = forward_chain(h, 0, first, n_des, u.I_des, u.I_cur, h->part, st);
+    else if (first != n_img) rc = forward_chain(h, first, n_img - first, n_des, u.I_des, u.I_cur, h->part + part_half, st);
+    h->desc_keys = -1;
+    return rc;
 }
 
 static int segment_tail(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs;
     int rc;
-    { Span sp(h, KC_DESCRIPTORS, st);
-      rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned,
-                              h->row_best, h->col_best, u.n_pairs * h->T, st); }
-    if (rc) return set_err(h, rc, "descriptor launch failed");
+    if (!desc_in_forward(h)) {
+        Span sp(h, KC_DESCRIPTORS, st);
+        rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned,
+                                h->row_best, h->col_best, u.n_pairs * h->T, st);
+        if (rc) return set_err(h, rc, "descriptor launch failed");
+    }
     { Span sp(h, KC_GRAM, st);
       rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");

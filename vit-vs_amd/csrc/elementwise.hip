@@ -150,13 +150,24 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
 // load of the row (x, every slice, the four parameter vectors) issued before the first add.
 constexpr int SMAX = 8;  // most K slices splitk_slices() ever picks
 
-template <typename T, int NV4, int LANES>
+enum RlnMode { RLN_PLAIN = 0, RLN_DESC = 1, RLN_EMBED = 2 };
+struct RlnExtra {   // by-value tail argument of the DESC / EMBED variants
+    DescOut desc;
+    const float* pos = nullptr;   // EMBED: position embedding [1 + T][D]
+    const float* cls = nullptr;   // EMBED: class token [D]
+};
+
+// MODE = RLN_EMBED finishes the patch embedding instead of a block: x (write-only) = pos_embed + split-K sum +
+// bias for the patch tokens (partial rows are [img][T], x rows [img][1 + T]), cls + pos[0] for the class
+// token, followed by block 0's norm1 — so neither the embedding epilogue nor a LayerNorm launch is needed.
+template <typename T, int NV4, int LANES, int MODE = RLN_PLAIN>
 __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, const float* __restrict__ part,
                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ out, int splits,
-                                                         int M, const float* __restrict__ ls, float eps) {
+                                                         int M, const float* __restrict__ ls, float eps, RlnExtra ex) {
     // argument order: the first 14 dwords are preloaded into SGPRs (kernarg preload); `ls` and `eps` are
     // fetched by the wave and first used after every other load is in flight
+    constexpr bool DESC = MODE == RLN_DESC;
     constexpr int D = 4 * NV4 * LANES;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x;
@@ -164,21 +175,49 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
     const int l = on ? lane : 0;
     float4* xr = reinterpret_cast<float4*>(x + (size_t)row * D);
     float4 v[NV4], pv[SMAX][NV4], bb[NV4], ll[NV4], gg[NV4], be[NV4];
+    if constexpr (MODE == RLN_EMBED) {
+        const int Tn = ex.desc.T, img = row / (Tn + 1), t = row - img * (Tn + 1) - 1;
+        const int Mp = (M / (Tn + 1)) * Tn;                       // rows of one partial slice
+        const int prow = img * Tn + max(t, 0);
+        const float4* posr = reinterpret_cast<const float4*>(ex.pos + (size_t)(1 + t) * D);
 #pragma unroll
-    for (int z = 0; z < SMAX; ++z)
-        if (z < splits) {
-            const float4* pz = reinterpret_cast<const float4*>(part + ((size_t)z * M + row) * D);
+        for (int z = 0; z < SMAX; ++z)
+            if (z < splits) {
+                const float4* pz = reinterpret_cast<const float4*>(part + ((size_t)z * Mp + prow) * D);
 #pragma unroll
-            for (int i = 0; i < NV4; ++i) pv[z][i] = pz[i * LANES + l];
-        }
+                for (int i = 0; i < NV4; ++i) pv[z][i] = pz[i * LANES + l];
+            }
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-        const int c = i * LANES + l;
-        v[i] = xr[c];
-        bb[i] = reinterpret_cast<const float4*>(bias)[c];
-        if (gamma) {
+        for (int i = 0; i < NV4; ++i) {
+            const int c = i * LANES + l;
+            v[i] = posr[c];
+            bb[i] = reinterpret_cast<const float4*>(t >= 0 ? bias : ex.cls)[c];
             gg[i] = reinterpret_cast<const float4*>(gamma)[c];
             be[i] = reinterpret_cast<const float4*>(beta)[c];
+        }
+        if (t < 0) {   // class token: cls + pos[0], no patch-embedding terms
+#pragma unroll
+            for (int z = 0; z < SMAX; ++z)
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) pv[z][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int z = 0; z < SMAX; ++z)
+            if (z < splits) {
+                const float4* pz = reinterpret_cast<const float4*>(part + ((size_t)z * M + row) * D);
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) pv[z][i] = pz[i * LANES + l];
+            }
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = i * LANES + l;
+            v[i] = xr[c];
+            bb[i] = reinterpret_cast<const float4*>(bias)[c];
+            if (gamma) {
+                gg[i] = reinterpret_cast<const float4*>(gamma)[c];
+                be[i] = reinterpret_cast<const float4*>(beta)[c];
+            }
         }
     }
     if (ls) {
@@ -201,6 +240,26 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
         if (on) xr[i * LANES + l] = r;
         v[i] = r;
         if (on) s += (r.x + r.y) + (r.z + r.w);
+    }
+    if constexpr (DESC) {
+        // last block: the row is final; emit its L2-normalised descriptor (patch tokens only) and clear the
+        // correspondence keys (same arithmetic and summation order as desc_plain_kernel)
+        const DescOut& desc = ex.desc;
+        const int gid = blockIdx.x * 64 + lane;
+        if (gid < desc.zero_count) { desc.zero_a[gid] = 0ull; desc.zero_b[gid] = 0ull; }
+        const int img = row / (desc.T + 1), t = row - img * (desc.T + 1) - 1;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i)
+            if (on) s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        const float nrm = fmaxf(sqrtf(wave_sum(s2)), 1e-8f);
+        if (t >= 0 && on) {
+            float4* dst = reinterpret_cast<float4*>(desc.dn + ((size_t)img * desc.T + t) * D);
+#pragma unroll
+            for (int i = 0; i < NV4; ++i)
+                dst[i * LANES + l] = make_float4(__fdiv_rn(v[i].x, nrm), __fdiv_rn(v[i].y, nrm), __fdiv_rn(v[i].z, nrm),
+                                                 __fdiv_rn(v[i].w, nrm));
+        }
     }
     if (!gamma) return;
     const float mean = wave_sum(s) / (float)D;
@@ -229,12 +288,12 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
     }
 }
 
-template <typename T>
+template <typename T, int MODE>
 static int launch_rln_t(float* x, const float* part, int splits, const float* bias, const float* ls, const float* g,
-                        const float* b, T* out, int M, int D, float eps, hipStream_t stream) {
-    dim3 grid(M), block(64);  // one wave per workgroup: 394 rows spread over all CUs
+                        const float* b, T* out, int M, int D, float eps, hipStream_t stream, const RlnExtra& ex) {
+    const dim3 grid(M), block(64);   // one wave per workgroup: 394 rows spread over all CUs
 #define VITVS_RLN(NV4, LANES) \
-    launch((residual_ln_kernel<T, NV4, LANES>), grid, block, 0, stream, x, part, bias, g, b, out, splits, M, ls, eps)
+    launch((residual_ln_kernel<T, NV4, LANES, MODE>), grid, block, 0, stream, x, part, bias, g, b, out, splits, M, ls, eps, ex)
     switch (D) {
         case 128: VITVS_RLN(1, 32); break;
         case 256: VITVS_RLN(1, 64); break;
@@ -247,11 +306,34 @@ static int launch_rln_t(float* x, const float* part, int splits, const float* bi
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+template <int MODE>
+static int launch_rln_p(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
+                        const float* g, const float* b, void* out, int M, int D, float eps, hipStream_t stream,
+                        const RlnExtra& ex) {
+    if (p == PREC_F32) return launch_rln_t<float, MODE>(x, part, splits, bias, ls, g, b, (float*)out, M, D, eps, stream, ex);
+    return launch_rln_t<bf16, MODE>(x, part, splits, bias, ls, g, b, (bf16*)out, M, D, eps, stream, ex);
+}
+
 int launch_residual_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
-                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream) {
+                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream,
+                       const DescOut* desc) {
     if (M <= 0 || splits < 1 || splits > SMAX) return -2;
-    if (p == PREC_F32) return launch_rln_t<float>(x, part, splits, bias, ls, gamma, beta, (float*)out, M, D, eps, stream);
-    return launch_rln_t<bf16>(x, part, splits, bias, ls, gamma, beta, (bf16*)out, M, D, eps, stream);
+    RlnExtra ex;
+    if (!desc) return launch_rln_p<RLN_PLAIN>(p, x, part, splits, bias, ls, gamma, beta, out, M, D, eps, stream, ex);
+    if (gamma || !desc->dn || desc->T <= 0 || M % (desc->T + 1) != 0 || desc->zero_count > M * 64) return -2;
+    ex.desc = *desc;
+    return launch_rln_p<RLN_DESC>(p, x, part, splits, bias, ls, gamma, beta, out, M, D, eps, stream, ex);
+}
+
+int launch_embed_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* pos,
+                    const float* cls, const float* gamma, const float* beta, void* out, int n_img, int T, int D, float eps,
+                    hipStream_t stream) {
+    if (n_img <= 0 || T <= 0 || splits < 1 || splits > SMAX || !gamma || !beta || !pos || !cls) return -2;
+    RlnExtra ex;
+    ex.desc.T = T;
+    ex.pos = pos;
+    ex.cls = cls;
+    return launch_rln_p<RLN_EMBED>(p, x, part, splits, bias, nullptr, gamma, beta, out, n_img * (T + 1), D, eps, stream, ex);
 }
 
 // ------------------------------------------------------------------------------------ descriptors

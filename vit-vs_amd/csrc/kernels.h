@@ -85,8 +85,24 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
                      float eps, hipStream_t stream);
 // x[m][:] += ls * (sum_z part[z][m][:] + bias)  (fixed slice order), then, if gamma != null,
 // out[m][:] = LayerNorm(x[m][:]) * gamma + beta in precision p.  One pass over the row.
+// desc (optional, only with gamma == null, i.e. after the last block): the same launch also writes the plain
+// L2-normalised descriptors dn[img][t][:] = x[img][1+t][:] / max(norm, 1e-8) (rows are [img][1+T] tokens, cls
+// first) and clears zero_count 64-bit words of zero_a / zero_b (the Gram kernel's atomicMax targets).
+struct DescOut {
+    float* dn = nullptr;
+    unsigned long long* zero_a = nullptr;
+    unsigned long long* zero_b = nullptr;
+    int T = 0;
+    int zero_count = 0;
+};
 int launch_residual_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
-                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream);
+                       const float* gamma, const float* beta, void* out, int M, int D, float eps, hipStream_t stream,
+                       const DescOut* desc = nullptr);
+// Finishes a split-K patch embedding (partial rows [n_img][T], launch_linear_partial) and applies block 0's norm1:
+//   x[img][0][:] = cls + pos[0];  x[img][1+t][:] = pos[1+t] + sum_z part[z][img*T+t][:] + bias;  out = LayerNorm(x).
+int launch_embed_ln(Precision p, float* x, const float* part, int splits, const float* bias, const float* pos,
+                    const float* cls, const float* gamma, const float* beta, void* out, int n_img, int T, int D, float eps,
+                    hipStream_t stream);
 // Descriptors for the correspondence stage, fp32, L2-normalised with max(|x|,1e-8):
 //   plain : dn[img][t][D]   = x[img][1+t][:] / max(norm, eps)
 //   binned: dn[img][t][9D]  = 3x3 replicate-clamped neighbourhood concat, then normalised.
