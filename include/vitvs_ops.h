@@ -5,6 +5,7 @@
  *   linear / linear_residual   nn.Linear (+ GELU, + LayerScale and residual add)  dino_patch/attention.py:72,79; block.py:78-96
  *   layernorm                  nn.LayerNorm(eps=1e-6)                              dino_patch/block.py:57,75
  *   attention                  scaled_dot_product_attention over [B,H,N,64]        dino_patch/attention.py:73-78
+ *   linear_partial+residual_ln the same nn.Linear + residual (+ next LayerNorm), as K slices  dino_patch/block.py:90-115
  * All pointers are device pointers; `precision` is enum vitvs_precision; `stream` a hipStream_t.
  */
 #ifndef VITVS_OPS_H
@@ -29,6 +30,18 @@ VITVS_API int vitvs_op_layernorm(int32_t precision, const float* x, const float*
 /* out[n_img*N][H*64] = softmax(q k^T / 8) v per (image, head); qkv [n_img*N][3*H*64] */
 VITVS_API int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
                        void* stream);
+
+/* Split-K pair used for the narrow layers (proj, fc2, patch embedding):
+ *   slices = vitvs_op_splitk_slices(precision, M, N, K)           (>= 1; the plan the forward uses)
+ *   part[z][M][N] (fp32) = A[:, z-th K slice] . W[:, z-th K slice]^T   for z < slices
+ *   x[M][D] (fp32) += ls[D] * (sum_z part[z] + bias)  (slices summed in index order); then, if gamma != NULL,
+ *   out[M][D] = LayerNorm(x) * gamma + beta in `precision` (out may be NULL when gamma is NULL). */
+VITVS_API int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K);
+VITVS_API int vitvs_op_linear_partial(int32_t precision, const void* A, const void* W, float* part, int32_t M, int32_t N,
+                            int32_t K, int32_t slices, void* stream);
+VITVS_API int vitvs_op_residual_ln(int32_t precision, float* x, const float* part, int32_t slices, const float* bias,
+                         const float* ls, const float* gamma, const float* beta, void* out, int32_t M, int32_t D,
+                         float eps, void* stream);
 
 #ifdef __cplusplus
 }

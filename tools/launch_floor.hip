@@ -1,0 +1,99 @@
+// Micro-benchmark of the per-launch cost of short dependent kernels on one stream (gfx950):
+// what does a launch cost as a function of grid size, workgroup size, LDS allocation and memory traffic?
+// Build:  hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=16 -o tools/launch_floor tools/launch_floor.hip
+// Run  :  HIP_FORCE_DEV_KERNARG=1 tools/launch_floor
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void k_empty(float* p) { if (p == nullptr && threadIdx.x == 12345) p[0] = 1.f; }
+
+__global__ void k_lds(float* p) {
+    extern __shared__ float s[];
+    if (p == nullptr && threadIdx.x == 12345) { s[threadIdx.x] = 1.f; p[0] = s[0]; }
+}
+
+// one dependent load -> store per thread (float4), like a LayerNorm row pass
+__global__ void k_copy(const float4* __restrict__ in, float4* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float4 v = in[i]; v.x += 1.f; out[i] = v; }
+}
+
+// writes `n` float4 without reading (dirty lines at the end of the kernel)
+__global__ void k_fill(float4* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+struct Timer {
+    std::vector<hipEvent_t> a, b;
+    explicit Timer(int n) : a(n), b(n) { for (int i = 0; i < n; ++i) { CHECK(hipEventCreate(&a[i])); CHECK(hipEventCreate(&b[i])); } }
+};
+
+template <class F>
+static void run(const char* name, int reps, hipStream_t st, F launch) {
+    Timer t(reps);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 20; ++i) launch(nullptr, nullptr);
+    CHECK(hipStreamSynchronize(st));
+    // pass 1: plain launches, chain time
+    CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) launch(nullptr, nullptr);
+    CHECK(hipEventRecord(e1, st));
+    CHECK(hipStreamSynchronize(st));
+    float chain_ms = 0.f;
+    CHECK(hipEventElapsedTime(&chain_ms, e0, e1));
+    // pass 2: per-kernel begin/end stamps
+    for (int i = 0; i < reps; ++i) launch(t.a[i], t.b[i]);
+    CHECK(hipStreamSynchronize(st));
+    double sum = 0.0, mn = 1e9;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, t.a[i], t.b[i]));
+        sum += ms; if (ms < mn) mn = ms;
+    }
+    printf("%-44s chain %6.2f us/launch   kernel avg %6.2f us  min %6.2f us\n", name, chain_ms * 1e3 / reps, sum * 1e3 / reps, mn * 1e3);
+}
+
+int main() {
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    const int n4 = 394 * 768 / 4;   // one fp32 activation matrix of the headline workload
+    float4 *bufa, *bufb, *big;
+    CHECK(hipMalloc(&bufa, (size_t)n4 * 16)); CHECK(hipMalloc(&bufb, (size_t)n4 * 16));
+    CHECK(hipMalloc(&big, (size_t)16 << 20));
+    CHECK(hipMemset(bufa, 0, (size_t)n4 * 16));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int reps = 400;
+#define L(kern, grid, block, lds, ...) [&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(kern, grid, block, lds, st, a, b, 0, __VA_ARGS__); }
+    run("empty 1 x 64", reps, st, L(k_empty, dim3(1), dim3(64), 0, (float*)bufa));
+    run("empty 256 x 64", reps, st, L(k_empty, dim3(256), dim3(64), 0, (float*)bufa));
+    run("empty 394 x 64", reps, st, L(k_empty, dim3(394), dim3(64), 0, (float*)bufa));
+    run("empty 252 x 256", reps, st, L(k_empty, dim3(252), dim3(256), 0, (float*)bufa));
+    run("empty 252 x 512", reps, st, L(k_empty, dim3(252), dim3(512), 0, (float*)bufa));
+    run("empty 252 x 1024", reps, st, L(k_empty, dim3(252), dim3(1024), 0, (float*)bufa));
+    run("empty 1024 x 256", reps, st, L(k_empty, dim3(1024), dim3(256), 0, (float*)bufa));
+    run("lds 48 KB 252 x 512", reps, st, L(k_lds, dim3(252), dim3(512), 48 * 1024, (float*)bufa));
+    run("lds 96 KB 252 x 512", reps, st, L(k_lds, dim3(252), dim3(512), 96 * 1024, (float*)bufa));
+    run("lds 160 KB 252 x 512", reps, st, L(k_lds, dim3(252), dim3(512), 160 * 1024, (float*)bufa));
+    run("copy 1.2 MB (394x768 f32) 296 x 256", reps, st, L(k_copy, dim3((n4 + 255) / 256), dim3(256), 0, bufa, bufb, n4));
+    run("copy 1.2 MB 1182 x 64", reps, st, L(k_copy, dim3((n4 + 63) / 64), dim3(64), 0, bufa, bufb, n4));
+    run("fill 1.2 MB 296 x 256", reps, st, L(k_fill, dim3((n4 + 255) / 256), dim3(256), 0, bufb, n4));
+    run("fill 4.8 MB 1182 x 256", reps, st, L(k_fill, dim3((4 * n4 + 255) / 256), dim3(256), 0, big, 4 * n4));
+    run("fill 16 MB 4096 x 256", reps, st, L(k_fill, dim3(4096), dim3(256), 0, big, 1 << 20));
+    // ping-pong: every launch reads what the previous one wrote (cross-XCD visibility on the critical path)
+    {
+        int flip = 0;
+        auto pp = [&](hipEvent_t a, hipEvent_t b) {
+            const float4* in = flip ? bufb : bufa; float4* out = flip ? bufa : bufb; flip ^= 1;
+            hipExtLaunchKernelGGL(k_copy, dim3((n4 + 255) / 256), dim3(256), 0, st, a, b, 0, in, out, n4);
+        };
+        run("copy ping-pong 1.2 MB 296 x 256", reps, st, pp);
+    }
+    return 0;
+}

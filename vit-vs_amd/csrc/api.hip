@@ -952,5 +952,18 @@ int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_
                        void* stream) {
     return launch_attention(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, qkv, out, n_img, N, H, as_stream(stream));
 }
+int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
+    return splitk_slices(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, M, N, K);
+}
+int vitvs_op_linear_partial(int32_t precision, const void* A, const void* W, float* part, int32_t M, int32_t N,
+                            int32_t K, int32_t slices, void* stream) {
+    return launch_linear_partial(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, part, M, N, K, slices, as_stream(stream));
+}
+int vitvs_op_residual_ln(int32_t precision, float* x, const float* part, int32_t slices, const float* bias,
+                         const float* ls, const float* gamma, const float* beta, void* out, int32_t M, int32_t D,
+                         float eps, void* stream) {
+    return launch_residual_ln(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, x, part, slices, bias, ls, gamma, beta, out, M, D,
+                              eps, as_stream(stream));
+}
 
 }  // extern "C"

@@ -15,12 +15,20 @@ template <typename T>
 __device__ __forceinline__ void store4(T* dst, f32x4 v);
 template <>
 __device__ __forceinline__ void store4<float>(float* dst, f32x4 v) {
+#ifdef VITVS_NT_STORE
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
 }
 template <>
 __device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
     bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#ifdef VITVS_NT_STORE
+    __builtin_nontemporal_store(h, reinterpret_cast<bf16x4*>(dst));
+#else
     *reinterpret_cast<bf16x4*>(dst) = h;
+#endif
 }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -107,16 +115,18 @@ struct EpiPartial {
     }
     __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4) const {
-        *reinterpret_cast<float4*>(part + ((size_t)blockIdx.z * M + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        store4<float>(part + ((size_t)blockIdx.z * M + m) * N + n, v);
     }
 };
 
 template <typename T, int BM, int BN, int KG, class Epi>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
-                                                          int i0) {
+                                                          int ks_i0) {
+    // ks_i0 = (K per split-K slice) << 16 | i0: one preloaded dword instead of gridDim.z (a hidden kernel
+    // argument the wave would have to fetch) and an integer division
     using Tile = GemmTile<BM, BN, KG>;
-    const Epi epi = Epi::make(out, c0, c1, M, N, i0);
+    const Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
@@ -127,11 +137,8 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     // copy, so the counted waits are unaffected, and their memory round trip is off the epilogue's path
     float4 col[Tile::NT];
 #pragma unroll
-    for (int ni = 0; ni < Tile::NT; ++ni) {
-        const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
-        if (!(KG == 2 && tile_owner<Tile::NT>(ni) != kg)) col[ni] = epi.column_terms(min(n, N - 4));
-    }
-    const int kslice = K / gridDim.z;
+    for (int ni = 0; ni < Tile::NT; ++ni) col[ni] = epi.column_terms(min(n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4), N - 4));
+    const int kslice = ks_i0 >> 16;
     gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
@@ -140,7 +147,11 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
+#ifdef VITVS_DBG_NO_EPI
+            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi(m, n, acc[ni][mi], col[ni]);
+#else
             if (m < M && n < N) epi(m, n, acc[ni][mi], col[ni]);
+#endif
         }
     }
 }
@@ -148,7 +159,9 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 static int k_tile(Precision p) { return (p == PREC_F32) ? 32 : 64; }
 
 static bool shapes_ok(Precision p, int M, int N, int K) {
-    return M > 0 && N > 0 && K > 0 && (K % k_tile(p)) == 0 && (N % 64) == 0;
+    const long long es = (p == PREC_F32) ? 4 : 2;   // operands are addressed with 32-bit byte offsets
+    return M > 0 && N > 0 && K > 0 && (K % k_tile(p)) == 0 && (N % 64) == 0 && (long long)M * K * es < (1ll << 32) &&
+           (long long)N * K * es < (1ll << 32);
 }
 
 // Tile plan.  In the one-frame-pair regime a launch cannot fill the chip, and a second wave of
@@ -194,8 +207,10 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
         raised = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
+    const int kslice = K / splits;
+    if (kslice >= 32768 || e.i0 < 0 || e.i0 > 0xffff) return -2;
     launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1, M,
-           N, K, e.i0);
+           N, K, (kslice << 16) | e.i0);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -48,13 +48,24 @@ struct GemmTile {
     static constexpr int L = ROWS / 32;                 // LDS-DMA instructions per wave per k-tile
     // ring stages per k-group.  (A 4-stage ring for the two-k-group tiles that fit the 160 KB of LDS
     // was measured 0.7 % SLOWER end to end at one frame pair: profiles/r01_notes.md.)
+#ifdef VITVS_LDS_BUDGET   // experiment switch (tools/op_chain): 4 stages wherever the rings fit this many bytes
+    static constexpr int NST = (KG * 4 * ROWS * 128 <= VITVS_LDS_BUDGET) ? 4 : 3;
+#else
     static constexpr int NST = (KG == 1) ? 4 : 3;
+#endif
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
-    static constexpr int LDS_BYTES = KG * GROUP_BYTES;
+    static constexpr int RING_BYTES = KG * GROUP_BYTES;
+    // two k-groups swap half of their accumulators through a region of its own (not the rings: no barrier is
+    // needed before the swap's writes while other waves still read their last stage)
+    static constexpr int SWAP_SLOTS = ((NT + 1) / 2) * MT;          // accumulator tiles a wave hands over
+    static constexpr int SWAP_BYTES = (KG == 2) ? SWAP_SLOTS * 16 * 512 : 0;
+    static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > 160 * 1024;   // no room: reuse the rings (one more barrier)
+    static constexpr int SWAP_OFFSET = SWAP_ALIAS ? 0 : RING_BYTES;
+    static constexpr int LDS_BYTES = SWAP_ALIAS ? (RING_BYTES > SWAP_BYTES ? RING_BYTES : SWAP_BYTES) : RING_BYTES + SWAP_BYTES;
     static constexpr int THREADS = 256 * KG;
     static_assert(ROWS % 32 == 0 && WN % 16 == 0 && WM % 16 == 0, "tile shape");
-    static_assert(KG == 1 || NT * MT * 16 * 256 <= GROUP_BYTES, "k-group reduction buffer must fit one ring");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 // With two k-groups, column tile ni of a wave is finished (reduced + epilogue) by this k-group.
@@ -91,8 +102,10 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
     const int nk = (k_end - k_begin) / (BK * KG);        // k-tiles per k-group
     const int kg_begin = k_begin + kg * nk * BK;
 
-    // per-lane source of each of this wave's L copy instructions (advances by BK elements per k-tile)
-    const T* src[L];
+    // per-lane source of each of this wave's L copy instructions: a wave-uniform base (A or W) plus a 32-bit
+    // byte offset that advances by 128 bytes per k-tile (operands are < 4 GiB; checked by the launchers)
+    const unsigned char* base[L];
+    unsigned off[L];
     int dst_off[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
@@ -100,10 +113,10 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         const int row = g8 * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         dst_off[j] = g8 * 1024;
-        if (g8 * 8 < BM)
-            src[j] = A + (size_t)min(m0 + row, m_rows - 1) * lda + kg_begin + c * EPC;
-        else
-            src[j] = W + (size_t)min(n0 + row - BM, n_rows - 1) * ldw + kg_begin + c * EPC;
+        const bool is_a = g8 * 8 < BM;           // wave-uniform
+        base[j] = reinterpret_cast<const unsigned char*>(is_a ? A : W);
+        const int r = is_a ? min(m0 + row, m_rows - 1) : min(n0 + row - BM, n_rows - 1);
+        off[j] = ((unsigned)r * (unsigned)(is_a ? lda : ldw) + (unsigned)kg_begin) * (unsigned)sizeof(T) + c * 16;
     }
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni)
@@ -114,7 +127,8 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         unsigned char* dst = ring + stage * Tile::STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < L; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(src[j] + (size_t)kt * BK), (lds_ptr)(dst + dst_off[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(base[j] + (off[j] + (unsigned)kt * 128u)), (lds_ptr)(dst + dst_off[j]), 16,
+                                             0, 0);
     };
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
@@ -127,11 +141,16 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         if (NST >= 4 && younger >= 2) wait_vmcnt<2 * L>();
         else if (younger >= 1) wait_vmcnt<L>();
         else wait_vmcnt<0>();
+#ifndef VITVS_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         // every wave has finished reading the stage tile kt - 1 used: refill it with tile kt + NST - 1
         if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
         const unsigned char* sa = ring + stage * Tile::STAGE_BYTES;
         const unsigned char* sb = sa + BM * 128;
+#ifdef VITVS_DBG_NO_LDSREAD
+        if (kt >= 0) { stage = (stage + 1 == NST) ? 0 : stage + 1; continue; }
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int c = 4 * s + (lane >> 4);
@@ -145,28 +164,37 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
 #pragma unroll
             for (int ni = 0; ni < Tile::NT; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = mma_chunk<T>(acc[ni][mi], wf[ni], xf[mi]);
+                for (int mi = 0; mi < Tile::MT; ++mi) {
+#ifdef VITVS_DBG_NO_MFMA
+                    acc[ni][mi][0] += __uint_as_float(wf[ni][0] ^ xf[mi][1]);
+#else
+                    acc[ni][mi] = mma_chunk<T>(acc[ni][mi], wf[ni], xf[mi]);
+#endif
+                }
         }
         stage = (stage + 1 == NST) ? 0 : stage + 1;
     }
     if constexpr (KG == 2) {
-        // The two k-groups exchange halves through LDS (the rings are idle after the barrier): each
-        // group ends up with the full sums of the column tiles it owns (tile_owner) and runs the
-        // epilogue for those only, so the epilogue work is shared by all 8 waves.
-        __syncthreads();
-        f32x4* buf = reinterpret_cast<f32x4*>(smem) + (wave * Tile::NT * Tile::MT) * 64 + lane;
+        // The two k-groups swap halves through LDS: each group ends up with the full sums of the column
+        // tiles it owns (tile_owner) and runs the epilogue for those only, so the epilogue work is shared by
+        // all 8 waves.  One barrier when the swap area is not part of the rings.
+        if constexpr (Tile::SWAP_ALIAS) __syncthreads();   // every wave is done reading the rings
+        f32x4* buf = reinterpret_cast<f32x4*>(smem + Tile::SWAP_OFFSET) + (wave_all * Tile::SWAP_SLOTS) * 64 + lane;
+        f32x4* peer = reinterpret_cast<f32x4*>(smem + Tile::SWAP_OFFSET) + ((wave_all ^ 4) * Tile::SWAP_SLOTS) * 64 + lane;
+        int slot = 0;
 #pragma unroll
         for (int ni = 0; ni < Tile::NT; ++ni)
             if (tile_owner<Tile::NT>(ni) != kg) {
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) buf[(ni * Tile::MT + mi) * 64] = acc[ni][mi];
+                for (int mi = 0; mi < Tile::MT; ++mi) buf[(slot++) * 64] = acc[ni][mi];
             }
         __syncthreads();
+        slot = 0;
 #pragma unroll
         for (int ni = 0; ni < Tile::NT; ++ni)
             if (tile_owner<Tile::NT>(ni) == kg) {
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] += buf[(ni * Tile::MT + mi) * 64];
+                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] += peer[(slot++) * 64];
             }
     }
 }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256 * KG) void linear_ln_kernel(const T* __restrict
     gemm_mainloop<T, 64, BN, KG>(A, W, K, K, M, N, m0, n0, 0, K, smem, acc);
 
     // merge the partial moments (Chan et al.), fixed order: within the thread, then across the 4 quarter lanes
-    float2* rowstat = reinterpret_cast<float2*>(smem + Tile::LDS_BYTES - 64 * sizeof(float2));
+    float2* rowstat = reinterpret_cast<float2*>(smem);   // ring stage 0: idle once every wave is past the main loop
     if (KG == 1) __syncthreads();   // the ring tail may still be read by a slower wave's last tile
     if (tid < 256) {
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
