@@ -29,6 +29,27 @@ __global__ void k_fill(float4* __restrict__ out, int n) {
     if (i < n) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+// 8 bytes per lane, 4 lanes cover a 32-byte segment of a row's 128-byte line, 4 passes complete the line:
+// the pattern of an MFMA-layout epilogue that stores bf16x4 per lane (rows = lane & 15 of a 16-row group)
+__global__ void k_fill_mfma_pattern(unsigned long long* __restrict__ out, int rows) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int row = wave * 16 + (lane & 15);
+    if (row >= rows) return;
+    unsigned long long* line = out + (size_t)row * 16;   // 128 B = 16 x 8 B
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) line[pass * 4 + (lane >> 4)] = 0x1234567812345678ull + pass;
+}
+// the same bytes as full 16-byte-per-lane rows: 8 lanes cover one 128-byte line
+__global__ void k_fill_rows(float4* __restrict__ out, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * 8) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+// dependent chain before the store: a load whose result feeds the stored value (store issued late)
+__global__ void k_load_then_fill_rows(const float4* __restrict__ in, float4* __restrict__ out, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * 8) { float4 v = in[i & 1023]; out[i] = v; }
+}
+
 struct Timer {
     std::vector<hipEvent_t> a, b;
     explicit Timer(int n) : a(n), b(n) { for (int i = 0; i < n; ++i) { CHECK(hipEventCreate(&a[i])); CHECK(hipEventCreate(&b[i])); } }
@@ -86,6 +107,12 @@ int main() {
     run("fill 1.2 MB 296 x 256", reps, st, L(k_fill, dim3((n4 + 255) / 256), dim3(256), 0, bufb, n4));
     run("fill 4.8 MB 1182 x 256", reps, st, L(k_fill, dim3((4 * n4 + 255) / 256), dim3(256), 0, big, 4 * n4));
     run("fill 16 MB 4096 x 256", reps, st, L(k_fill, dim3(4096), dim3(256), 0, big, 1 << 20));
+    {
+        const int rows = 394 * 18;   // 394 x 2304 bf16 = 18 lines of 128 B per token row: the qkv output (1.8 MB)
+        run("store 1.8 MB, MFMA pattern (8 B/lane, 32-B runs)", reps, st, L(k_fill_mfma_pattern, dim3((rows / 16 * 64 + 255) / 256 + 1), dim3(256), 0, (unsigned long long*)big, rows));
+        run("store 1.8 MB, full rows (16 B/lane)", reps, st, L(k_fill_rows, dim3((rows * 8 + 255) / 256), dim3(256), 0, big, rows));
+        run("load then store 1.8 MB, full rows", reps, st, L(k_load_then_fill_rows, dim3((rows * 8 + 255) / 256), dim3(256), 0, bufa, big, rows));
+    }
     // ping-pong: every launch reads what the previous one wrote (cross-XCD visibility on the critical path)
     {
         int flip = 0;

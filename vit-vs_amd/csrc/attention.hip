@@ -108,8 +108,7 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
                 acc_s[t4][r] = x;
                 mloc = fmaxf(mloc, x);
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, WAVE));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, WAVE));
+        mloc = rows_max(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = fast_exp2(m_run - m_new);
         m_run = m_new;
@@ -148,36 +147,35 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
         }
     }
     if constexpr (KS >= 2) {
-        // merge the key groups' online-softmax states: groups 1 .. KS-1 -> LDS -> group 0 (fixed order)
+        // merge the key groups' online-softmax states: groups 1 .. KS-1 -> LDS -> group 0 (fixed order);
+        // 5 x 16 bytes per lane (O^T accumulators, then max and sum), lane-major
         __syncthreads();
-        float* buf = reinterpret_cast<float*>(smem) + (wave * 64 + lane);   // [KS-1][18][256] floats, lane-major
+        f32x4* buf = reinterpret_cast<f32x4*>(smem) + (wave * 64 + lane);   // [KS-1][5][256] x 16 B
         if (kgp >= 1) {
-            float* mine = buf + (kgp - 1) * 18 * 256;
-            mine[0 * 256] = m_run;
-            mine[1 * 256] = l_run;
+            f32x4* mine = buf + (kgp - 1) * 5 * 256;
 #pragma unroll
-            for (int td = 0; td < 4; ++td)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(2 + td * 4 + r) * 256] = acc_o[td][r];
+            for (int td = 0; td < 4; ++td) mine[td * 256] = acc_o[td];
+            mine[4 * 256] = f32x4{m_run, l_run, 0.f, 0.f};
         }
         __syncthreads();
         if (kgp >= 1) return;
 #pragma unroll
         for (int o = 0; o < KS - 1; ++o) {
-            const float* other = buf + o * 18 * 256;
-            const float m_b = other[0 * 256], l_b = other[1 * 256];
-            const float m_tot = fmaxf(m_run, m_b);
-            const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(m_b - m_tot);
+            const f32x4* other = buf + o * 5 * 256;
+            const f32x4 ml = other[4 * 256];
+            const float m_tot = fmaxf(m_run, ml[0]);
+            const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(ml[0] - m_tot);
             m_run = m_tot;
-            l_run = l_run * wa + l_b * wb;
+            l_run = l_run * wa + ml[1] * wb;
 #pragma unroll
-            for (int td = 0; td < 4; ++td)
+            for (int td = 0; td < 4; ++td) {
+                const f32x4 ob = other[td * 256];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + other[(2 + td * 4 + r) * 256] * wb;
+                for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + ob[r] * wb;
+            }
         }
     }
-    l_run += __shfl_xor(l_run, 16, WAVE);
-    l_run += __shfl_xor(l_run, 32, WAVE);
+    l_run = rows_sum(l_run);
     const float inv = 1.0f / l_run;
     if (q < N) {
         bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
@@ -262,8 +260,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 acc_s[t4][r] = x;
                 mloc = fmaxf(mloc, x);
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, WAVE));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, WAVE));
+        mloc = rows_max(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = exp2f(m_run - m_new);
         m_run = m_new;
@@ -294,8 +291,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 }
             }
     }
-    l_run += __shfl_xor(l_run, 16, WAVE);
-    l_run += __shfl_xor(l_run, 32, WAVE);
+    l_run = rows_sum(l_run);
     const float inv = 1.0f / l_run;
     if (q < N) {
         float* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
@@ -313,6 +309,8 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
+    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && getenv("VITVS_ATTN_KS4")) {   // experiment switch
+        launch(attention_bf16_kernel<4>, grid, dim3(1024), 4 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch(attention_bf16_kernel<2>, grid, dim3(512), 2 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else {

@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;  // 16-byte register image (native vector: stays in VGPRs)
 
 constexpr int WAVE = 64;
@@ -20,26 +21,113 @@ template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; };
 template <> struct Elem<bf16> { static constexpr int PER_CHUNK = 8; };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+// Cross-lane reductions on the VALU (DPP row operations, v_readlane and gfx950's v_permlane{16,32}_swap):
+// the HIP __shfl_* intrinsics go through the LDS crossbar (ds_bpermute, ~100+ cycles of latency per step; a
+// 6-step butterfly is ~0.3 us), which is most of the run time of a one-wave LayerNorm row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned v) {   // lanes outside ROW_MASK (or with no source) get `old`
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __uint_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_uint(old), __float_as_uint(v)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double v) {
+    const unsigned long long o = __builtin_bit_cast(unsigned long long, old), x = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = dpp_mov<CTRL, ROW_MASK>((unsigned)o, (unsigned)x);
+    const unsigned hi = dpp_mov<CTRL, ROW_MASK>((unsigned)(o >> 32), (unsigned)(x >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;               // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;     // lane i <-> 7-i within 8, i <-> 15-i within 16
+constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;        // last lane of a row -> the next row / rows 2,3
+
+// Sum over the 64 lanes, returned to every lane (wave-uniform).  Fixed order: pairs, quads, 8, 16, rows.
+template <typename F>
+__device__ __forceinline__ F wave_sum_dpp(F v) {
+    v += dpp_mov<DPP_XOR1, 0xF>(F(0), v);
+    v += dpp_mov<DPP_XOR2, 0xF>(F(0), v);
+    v += dpp_mov<DPP_HALF_MIRROR, 0xF>(F(0), v);
+    v += dpp_mov<DPP_MIRROR, 0xF>(F(0), v);
+    v += dpp_mov<DPP_BCAST15, 0xA>(F(0), v);
+    v += dpp_mov<DPP_BCAST31, 0xC>(F(0), v);
+    return v;   // lane 63 holds the total
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = wave_sum_dpp(v);
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v += (int)dpp_mov<DPP_XOR1, 0xF>(0u, (unsigned)v);
+    v += (int)dpp_mov<DPP_XOR2, 0xF>(0u, (unsigned)v);
+    v += (int)dpp_mov<DPP_HALF_MIRROR, 0xF>(0u, (unsigned)v);
+    v += (int)dpp_mov<DPP_MIRROR, 0xF>(0u, (unsigned)v);
+    v += (int)dpp_mov<DPP_BCAST15, 0xA>(0u, (unsigned)v);
+    v += (int)dpp_mov<DPP_BCAST31, 0xC>(0u, (unsigned)v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v = wave_sum_dpp(v);
+    const unsigned long long x = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    const float ninf = -__builtin_huge_valf();
+    v = fmaxf(v, dpp_mov<DPP_XOR1, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_mov<DPP_MIRROR, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_mov<DPP_BCAST15, 0xA>(ninf, v));
+    v = fmaxf(v, dpp_mov<DPP_BCAST31, 0xC>(ninf, v));
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+// The value held by lane ^ 16 / lane ^ 32 (v_permlane16_swap / v_permlane32_swap of two copies of v).
+__device__ __forceinline__ unsigned lane_xor16(unsigned v) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return ((threadIdx.x >> 4) & 1) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned lane_xor32(unsigned v) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return ((threadIdx.x >> 5) & 1) ? r[0] : r[1];
+}
+__device__ __forceinline__ float lane_xor16(float v) { return __uint_as_float(lane_xor16(__float_as_uint(v))); }
+__device__ __forceinline__ float lane_xor32(float v) { return __uint_as_float(lane_xor32(__float_as_uint(v))); }
+// Reductions over the 4 rows of 16 lanes (same lane & 15), result in all 4: sum / max of {v, r[0], r[1]} needs no select
+__device__ __forceinline__ float rows_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_xor(lo, o, WAVE);
-    hi = __shfl_xor(hi, o, WAVE);
+    if (o == 16) { lo = lane_xor16(lo); hi = lane_xor16(hi); }
+    else if (o == 32) { lo = lane_xor32(lo); hi = lane_xor32(hi); }
+    else { lo = __shfl_xor(lo, o, WAVE); hi = __shfl_xor(hi, o, WAVE); }
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// max of a 64-bit key over the 16 lanes of a DPP row (lane & 15), result in all 16
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long key) {
+    const unsigned lo = dpp_mov<CTRL, 0xF>(0u, (unsigned)key), hi = dpp_mov<CTRL, 0xF>(0u, (unsigned)(key >> 32));
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return (o > key) ? o : key;
+}
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long key) {
+    key = dpp_max_u64<DPP_XOR1>(key);
+    key = dpp_max_u64<DPP_XOR2>(key);
+    key = dpp_max_u64<DPP_HALF_MIRROR>(key);
+    return dpp_max_u64<DPP_MIRROR>(key);
 }
 
 // LDS operand tile: rows of 128 bytes (8 chunks of 16 B).  Chunk c of row r lives at

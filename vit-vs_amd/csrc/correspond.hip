@@ -71,11 +71,7 @@ __global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const float* __re
                 const unsigned long long k = (i < T) ? pack_best(acc[ni][mi][r], (unsigned)i) : 0ull;
                 key = (k > key) ? k : key;
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const unsigned long long k = shfl_xor_u64(key, o);
-                key = (k > key) ? k : key;
-            }
+            key = row16_max_u64(key);
             if ((lane & 15) == 0 && j < T) atomicMax(cb + j, key);
         }
 }

@@ -40,13 +40,11 @@ __device__ __forceinline__ void store4t<bf16>(bf16* dst, float a, float b, float
 // wave hold 4 consecutive columns each.  Every lane of the wave must call this (shuffles).
 __device__ __forceinline__ void write_moments16(float4 r, bool valid, float* stats, int m, int np, int p) {
     float s = (r.x + r.y) + (r.z + r.w);
-    s += __shfl_xor(s, 16, WAVE);
-    s += __shfl_xor(s, 32, WAVE);
+    s = rows_sum(s);
     const float mean = s * 0.0625f;
     const float a = r.x - mean, b = r.y - mean, c = r.z - mean, d = r.w - mean;
     float q = (a * a + b * b) + (c * c + d * d);
-    q += __shfl_xor(q, 16, WAVE);
-    q += __shfl_xor(q, 32, WAVE);
+    q = rows_sum(q);
     if (valid && (threadIdx.x & 48) == 0) *reinterpret_cast<float2*>(stats + ((size_t)m * np + p) * 2) = make_float2(s, q);
 }
 

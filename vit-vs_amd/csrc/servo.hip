@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void servo_kernel(const unsigned long long* __
         flag[i] = same_image ? 1 : m;
         cnt += m;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    cnt = wave_sum(cnt);
     if (lane == 0) iscr[wave] = cnt;
     lds_barrier();
     const int n_mutual = iscr[0] + iscr[1] + iscr[2] + iscr[3];
@@ -155,10 +154,15 @@ __global__ __launch_bounds__(256) void servo_kernel(const unsigned long long* __
             local += flag[i];
         }
         int incl = local;
+        if (per == 1) {   // one position per thread: the wave scan is a ballot and a bit count (no LDS-crossbar shuffles)
+            const unsigned long long mask = __ballot(local != 0);
+            incl = local + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        } else {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, WAVE);
+                if (lane >= o) incl += up;
+            }
         }
         if (lane == 63) iscr[4 + wave] = incl;
         lds_barrier();
