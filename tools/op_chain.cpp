@@ -79,6 +79,48 @@ int main(int argc, char** argv) {
     run("fc2   partial 394x768x3072", st, reps, [&] { return vitvs_op_linear_partial(prec, hid, wfc2, part, M, D, hidden, s_fc2, st); });
     run("residual_ln (fc2 slices) + LayerNorm", st, reps, [&] { return vitvs_op_residual_ln(prec, x, part, s_fc2, bias, nullptr, gamma, beta, xn, M, D, 1e-6f, st); });
     run("layernorm 394x768", st, reps, [&] { return vitvs_op_layernorm(prec, x, gamma, beta, xn, M, D, 1e-6f, st); });
+    // kernel-switch cost: alternate two different kernels with no data dependence between them
+    run("pair: qkv, layernorm (independent)", st, reps / 2, [&] {
+        int rc = vitvs_op_linear(prec, xn, wqkv, bias, qkv, M, 3 * D, D, 0, st);
+        rc |= vitvs_op_layernorm(prec, x, gamma, beta, attn, M, D, 1e-6f, st);
+        return rc;
+    });
+    run("pair: layernorm -> qkv (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_layernorm(prec, x, gamma, beta, xn, M, D, 1e-6f, st);
+        rc |= vitvs_op_linear(prec, xn, wqkv, bias, qkv, M, 3 * D, D, 0, st);
+        return rc;
+    });
+    run("pair: qkv -> attention (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_linear(prec, xn, wqkv, bias, qkv, M, 3 * D, D, 0, st);
+        rc |= vitvs_op_attention(prec, qkv, attn, 2, N, H, st);
+        return rc;
+    });
+    void* qkv2 = dalloc((size_t)M * 3 * D * es, 0);
+    run("pair: qkv, attention (independent buffers)", st, reps / 2, [&] {
+        int rc = vitvs_op_linear(prec, xn, wqkv, bias, qkv, M, 3 * D, D, 0, st);
+        rc |= vitvs_op_attention(prec, qkv2, attn, 2, N, H, st);
+        return rc;
+    });
+    run("pair: attention -> proj partial (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_attention(prec, qkv, attn, 2, N, H, st);
+        rc |= vitvs_op_linear_partial(prec, attn, wproj, part, M, D, D, s_proj, st);
+        return rc;
+    });
+    run("pair: fc1 -> fc2 partial (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_linear(prec, xn, wfc1, bias, hid, M, hidden, D, 1, st);
+        rc |= vitvs_op_linear_partial(prec, hid, wfc2, part, M, D, hidden, s_fc2, st);
+        return rc;
+    });
+    run("pair: residual_ln -> fc1 (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_residual_ln(prec, x, part, s_fc2, bias, nullptr, gamma, beta, xn, M, D, 1e-6f, st);
+        rc |= vitvs_op_linear(prec, xn, wfc1, bias, hid, M, hidden, D, 1, st);
+        return rc;
+    });
+    run("pair: fc2 partial -> residual_ln (dependent)", st, reps / 2, [&] {
+        int rc = vitvs_op_linear_partial(prec, hid, wfc2, part, M, D, hidden, s_fc2, st);
+        rc |= vitvs_op_residual_ln(prec, x, part, s_fc2, bias, nullptr, gamma, beta, xn, M, D, 1e-6f, st);
+        return rc;
+    });
     // one whole block as the forward issues it (7 launches)
     run("block (7 launches)", st, reps / 4, [&] {
         int rc = vitvs_op_linear(prec, xn, wqkv, bias, qkv, M, 3 * D, D, 0, st);

@@ -51,6 +51,7 @@ struct EpiStore {
     const float* bias;
     int ldo;
     int gelu;
+    __device__ __forceinline__ void set_slice(int) {}
     __device__ __forceinline__ static EpiStore make(void* out, const float* c0, const float*, int, int N, int i0) {
         return EpiStore{(T*)out, c0, N, i0};
     }
@@ -70,6 +71,7 @@ struct EpiResidual {
     const float* bias;
     const float* ls;  // may be null
     int ld;
+    __device__ __forceinline__ void set_slice(int) {}
     __device__ __forceinline__ static EpiResidual make(void* out, const float* c0, const float* c1, int, int N, int) {
         return EpiResidual{(float*)out, c0, c1, N};
     }
@@ -92,6 +94,7 @@ struct EpiPatch {
     const float* bias;
     const float* pos;
     int T, D;
+    __device__ __forceinline__ void set_slice(int) {}
     __device__ __forceinline__ static EpiPatch make(void* out, const float* c0, const float* c1, int, int N, int i0) {
         return EpiPatch{(float*)out, c0, c1, i0, N};
     }
@@ -114,8 +117,9 @@ struct EpiPartial {
         return EpiPartial{(float*)out, M, N};
     }
     __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void set_slice(int z) { part += (size_t)z * M * N; }
     __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4) const {
-        store4<float>(part + ((size_t)blockIdx.z * M + m) * N + n, v);
+        store4<float>(part + (size_t)m * N + n, v);
     }
 };
 
@@ -123,12 +127,31 @@ template <typename T, int BM, int BN, int KG, class Epi>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
                                                           int ks_i0) {
-    // ks_i0 = (K per split-K slice) << 16 | i0: one preloaded dword instead of gridDim.z (a hidden kernel
-    // argument the wave would have to fetch) and an integer division
+    // ks_i0 packs [31:24] K per split-K slice / 32, [23:20] slices, [19:16] tile map, [15:0] i0: one preloaded
+    // dword instead of gridDim (hidden kernel arguments the wave would have to fetch) and an integer division.
     using Tile = GemmTile<BM, BN, KG>;
-    const Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
+    Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const unsigned pk = (unsigned)ks_i0;
+    const int kslice = (int)(pk >> 24) * 32, nz = (pk >> 20) & 15, map = (pk >> 16) & 15;
+    int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
+    if (map != 0) {
+        // XCD-aware tile map (1-D grid).  Workgroup id i runs on XCD i % 8, and every XCD has its own L2: the 8th of
+        // the tiles an XCD gets is made a compact block of the (column, row x slice) grid - 2^(map-1) column groups,
+        // rows within a group, columns within a row - so that an activation block (fresh from the previous launch,
+        // i.e. read from HBM) is fetched by 1-2 XCDs instead of all 8, at the price of more XCDs per weight block.
+        const int nx = N / BN, ny = (M + BM - 1) / BM, nyy = ny * nz, tiles = nx * nyy, per = (tiles + 7) >> 3;
+        const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (lin >= tiles) return;
+        const int cw = nx >> (map - 1);
+        const int cg = lin / (nyy * cw), rem = lin - cg * nyy * cw;
+        const int yy = rem / cw;
+        tx = cg * cw + (rem - yy * cw);
+        tz = yy / ny;
+        ty = yy - tz * ny;
+    }
+    epi.set_slice(tz);
+    const int m0 = ty * BM, n0 = tx * BN;
     f32x4 acc[Tile::NT][Tile::MT];
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;
@@ -138,8 +161,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     float4 col[Tile::NT];
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) col[ni] = epi.column_terms(min(n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4), N - 4));
-    const int kslice = ks_i0 >> 16;
-    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, blockIdx.z * kslice, (blockIdx.z + 1) * kslice, smem, acc);
+    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc);
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
         if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
@@ -208,9 +230,22 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
     }
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
     const int kslice = K / splits;
-    if (kslice >= 32768 || e.i0 < 0 || e.i0 > 0xffff) return -2;
+    if (kslice % 32 != 0 || kslice / 32 > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff) return -2;
+    // tile map: 0 = plain 3-D grid; m >= 1 = XCD-aware 1-D grid with 2^(m-1) column groups (one-wave launches only)
+    int map = 0;
+    const long tiles = (long)grid.x * grid.y * grid.z;
+    if (tiles <= 256) {
+        static const int forced = getenv("VITVS_GEMM_MAP") ? atoi(getenv("VITVS_GEMM_MAP")) : -1;
+        // measured (tools/op_chain pairs, profiles/r01_notes.md): the map pays for the split-K layers, whose activation
+        // operand is large relative to their run time (fc1 -> fc2: -0.85 us, attention -> proj: -0.3 us), and costs
+        // 0.4-0.6 us on qkv / fc1, whose weight blocks would be fetched by 4 XCDs instead of 2
+        // end to end the plain grid wins (2106 vs 2093 updates/s), so the map stays an experiment switch
+        map = forced >= 0 ? forced : 0;
+        while (map > 1 && (grid.x % (1u << (map - 1))) != 0) --map;
+        if (map) grid = dim3((unsigned)(8 * ((tiles + 7) / 8)));
+    }
     launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1, M,
-           N, K, (kslice << 16) | e.i0);
+           N, K, (int)(((unsigned)(kslice / 32) << 24) | ((unsigned)splits << 20) | ((unsigned)map << 16) | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
