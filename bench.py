@@ -5,7 +5,7 @@ One "step" = one compute_velocity update per GPU: both frames forwarded through 
 recomputed, as the reference does), dense cosine correspondence, mutual-NN filter, 24 features drawn
 in a fresh random visiting order, interaction matrix, pseudo-inverse -> v_c.  Inputs (frames, depth,
 intrinsics, weights, one visiting order per update) are resident in HBM before the timed region; each step is
-enqueued without host synchronisation (≈ 90 stream launches), and with N > 1
+enqueued without host synchronisation (86 stream launches), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--pairs B] [--config KEY]
@@ -57,20 +57,51 @@ def kernel_work(cfg, n_img, n_pairs, es, binned):
     s_avg = (s_proj + s_fc2) / 2
     dp = d * (9 if binned else 1)
     kp = -(-cfg.patch_k // 64) * 64
+    s_pe = split_k(n_img * t, d, kp, bk)
     return {
         "patchify": (0.0, n_img * cfg.img_size ** 2 * 3 + n_img * t * kp * es),
-        "patch_embed": (2.0 * n_img * t * cfg.patch_k * d, n_img * t * kp * es + d * kp * es + n_img * t * d * 4),
-        "layernorm": (8.0 * m * d, m * d * (4 + es)),
+        # split-K patch embedding, finished (with cls / pos_embed / block 0's norm1) by the "layernorm" class
+        "patch_embed": (2.0 * n_img * t * cfg.patch_k * d, n_img * t * kp * es + d * kp * es + s_pe * n_img * t * d * 4),
+        "layernorm": (10.0 * m * d, s_pe * n_img * t * d * 4 + n * d * 4 + m * d * (4 + es)),
         "qkv": (2.0 * m * 3 * d * d, (m * d + 3 * d * d + m * 3 * d) * es),
         "attention": (4.0 * n_img * n * n * d, (m * 3 * d + m * d) * es),
         "proj": (2.0 * m * d * d, (m * d + d * d) * es + s_proj * m * d * 4),
         "fc1": (2.0 * m * h * d, (m * d + h * d + m * h) * es),
         "fc2": (2.0 * m * d * h, (m * h + d * h) * es + s_fc2 * m * d * 4),
-        "residual_ln": (12.0 * m * d, m * d * (4 + 4 * s_avg + 4 + es)),
-        "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),
+        "residual_ln": (12.0 * m * d, m * d * (4 + 4 * s_avg + 4 + es)),   # the last one also writes the descriptors
+        "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),    # binned descriptors only
         "gram_argmax": (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4),
         "servo": (0.0, n_pairs * t * 16),
     }
+
+
+def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
+    """Per-launch time of the split-K GEMM in a chain of PLAIN launches (no per-launch events).  Event-stamped
+    launches (the instrumented pass, rocprofv3) read ~1.7 us longer per launch than the same kernel costs in the
+    un-instrumented stream (tools/launch_floor.hip), so this is the figure that adds up to `ms_per_step`."""
+    import ctypes as C
+    lib = _lib.load()
+    code = _lib.BF16 if prec == "bf16" else _lib.F32
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    a = torch.zeros((m, k), dtype=dt, device=dev)
+    ws = [torch.zeros((n, k), dtype=dt, device=dev) for _ in range(12)]   # 12 weight sets, like the 12 blocks
+    part = torch.zeros((slices, m, n), dtype=torch.float32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def chain(r):
+        for i in range(r):
+            lib.vitvs_op_linear_partial(code, C.c_void_p(a.data_ptr()), C.c_void_p(ws[i % 12].data_ptr()),
+                                        C.c_void_p(part.data_ptr()), m, n, k, slices, st)
+    chain(20)
+    torch.cuda.synchronize(dev)
+    best = float("inf")
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        chain(reps)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
 
 
 def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=20.0):
@@ -108,6 +139,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="vitb16_224", choices=sorted(config.BASELINE_CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plain-chain", action="store_true",
+                    help="skip the plain-launch chain of the dominant GEMM (profiler runs: keeps the kernel trace to the steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +236,11 @@ def main():
             step(args.warmup + i)
         prof = eng.timing_collect()
         eng.timing_enable(False)
+        plain = None
+        if rank == 0 and not args.no_plain_chain:
+            m_rows, bk_ = 2 * B * cfg.seq, 128 // (2 if args.precision == "bf16" else 4)
+            plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_), dev)
+                     for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
     updates = world * B * args.steps
     value = updates / elapsed
@@ -247,6 +285,11 @@ def main():
                     unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic,
                     algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
                     avg_launch_us=round(avg_s * 1e6, 3), event_pair_overhead_us=round(overhead_s * 1e6, 3))
+        if plain and dom == "linear_partial(proj+fc2)":
+            # the same kernel in a chain of plain launches (what the un-instrumented step pays per launch)
+            p_us = sum(plain[c] * kernels[c]["launches_per_step"] for c in members) / launches
+            roof.update(plain_launch_us=round(p_us, 3), achieved_plain=round(fl / (p_us * 1e-6) / 1e12, 3),
+                        frac_plain=round(fl / (p_us * 1e-6) / peak, 5))
     else:
         roof = dict(kernel=symbol, classes=members, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9,
                     unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic,
