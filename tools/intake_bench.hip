@@ -12,7 +12,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-enum Mode { ROWS_DMA = 0, TILED_W_DMA = 1, TILED_BOTH_DMA = 2, ROWS_VGPR = 3, SAME_SLAB_DMA = 4, TILED_BOTH_VGPR = 5 };
+enum Mode { ROWS_DMA = 0, TILED_W_DMA = 1, TILED_BOTH_DMA = 2, ROWS_VGPR = 3, SAME_SLAB_DMA = 4, TILED_BOTH_VGPR = 5, ROWS_DMA_SWZ = 6 };
 
 // grid (N/64, ceil(M/64)), WAVES waves.  Per k-tile (64 bf16 = 128 B per row) the workgroup copies 64 A rows and
 // 64 W rows (16 KB).  ROWS: row-major operands with pitch K*2 bytes (what the GEMM does).  TILED: the 64x128-byte
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64 * WAVES) void intake_kernel(const unsigned char*
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int g8 = wave * L + j;         // 0..7: A rows, 8..15: W rows
-        const int row = (g8 & 7) * 8 + (lane >> 3), c = lane & 7;
+        const int row = (g8 & 7) * 8 + (lane >> 3);
+        const int c = (MODE == ROWS_DMA_SWZ) ? ((lane & 7) ^ ((row >> 1) & 7)) : (lane & 7);   // SWZ: the GEMM's source-side LDS swizzle
         const bool isA = g8 < 8;
         const bool tiled = (MODE == TILED_BOTH_DMA || MODE == TILED_BOTH_VGPR) || (MODE == TILED_W_DMA && !isA);
         const unsigned char* base = isA ? A : W;
@@ -118,6 +119,8 @@ int main() {
                K, (N / 64) * 7, 128.0 * K * 2 / 1024);
         run<ROWS_DMA, 8, 2>("row-major, LDS-DMA, 8 waves, 2 tiles in flight", st, A, W, M, N, K, sink, fl);
         run<ROWS_DMA, 8, 4>("row-major, LDS-DMA, 8 waves, 4 in flight", st, A, W, M, N, K, sink, fl);
+        run<ROWS_DMA_SWZ, 8, 2>("row-major, swizzled chunks, LDS-DMA, 8 waves, 2 in flight", st, A, W, M, N, K, sink, fl);
+        run<ROWS_DMA_SWZ, 8, 4>("row-major, swizzled chunks, LDS-DMA, 8 waves, 4 in flight", st, A, W, M, N, K, sink, fl);
         run<ROWS_DMA, 8, 6>("row-major, LDS-DMA, 8 waves, 6 in flight", st, A, W, M, N, K, sink, fl);
         run<ROWS_DMA, 4, 4>("row-major, LDS-DMA, 4 waves, 4 in flight", st, A, W, M, N, K, sink, fl);
         run<ROWS_DMA, 16, 4>("row-major, LDS-DMA, 16 waves, 4 in flight", st, A, W, M, N, K, sink, fl);

@@ -188,6 +188,141 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
     }
 }
 
+// ------------------------------------------------------------------------------------ bf16, short sequences
+// N <= 256 (the 197 tokens of a 224² frame): one workgroup = 16 queries of one (image, head), wave w = key tile w.
+// Every wave requests its whole input at entry in one memory round trip — Q and its 64 keys straight into MFMA
+// operand registers, its 64 values into a wave-private LDS slab by LDS-DMA (read back transposed) — and runs the
+// score -> softmax -> PV chain for ONE tile; the four (max, sum, O) states are merged in parallel, wave w
+// finishing head dims 16w .. 16w+15.  No barrier before the merge, a quarter of the 64-query kernel's serial chain.
+__global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                   int N, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 15, g = lane >> 4;
+    const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
+    // Addresses: wave-uniform base pointer + 32-bit byte offsets built from 24-bit multiplies (the kernel is a
+    // chain of latencies: ~150 instructions of 64-bit address arithmetic before the first request cost 0.4 us).
+    const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
+    const unsigned row_bytes = 6u * (unsigned)D;                                 // 3D bf16 per token row
+    const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 128u;   // q of this (image, head)
+    const unsigned k_off = head_off + 2u * (unsigned)D, v_off = head_off + 4u * (unsigned)D;
+    unsigned char* ldsV = smem + wave * 8192;                                  // [64 keys][128 B], this wave's tile
+    f32x4* mbuf = reinterpret_cast<f32x4*>(smem + 4 * 8192);                   // [4 waves][5][64 lanes] x 16 B
+    const int kb = wave * 64;
+    const bool active = kb < N;                                                // wave-uniform
+    const int q = q0 + qi;
+    const unsigned lane_col = 16u * (unsigned)g;
+    bf16x8 qf[2], kf[4][2];
+    {
+        const unsigned o = head_off + __umul24((unsigned)min(q, N - 1), row_bytes) + lane_col;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
+    }
+    if (active) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const unsigned o = k_off + __umul24((unsigned)min(kb + 16 * t4 + qi, N - 1), row_bytes) + lane_col;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[t4][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned o = v_off + __umul24((unsigned)min(kb + 8 * j + (lane >> 3), N - 1), row_bytes) + 16u * (lane & 7);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + o), (lds_ptr)(ldsV + j * 1024), 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every request is issued before anything waits on one
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    if (active) {
+        f32x4 acc_s[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t4][s], qf[s], acc_s[t4], 0, 0, 0);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + 16 * t4 + 4 * g + r;
+                float x = acc_s[t4][r] * kScaleLog2e;
+                x = (key < N) ? x : -INFINITY;
+                acc_s[t4][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        m_run = rows_max(mloc);               // the tile's first key is valid (kb < N), so this is finite
+        float psum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(acc_s[t4][r] - m_run);
+                acc_s[t4][r] = p;
+                psum += p;
+            }
+        l_run = rows_sum(psum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's V slab has landed (its own LDS-DMA copies)
+        // O^T = V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const int k0 = 32 * u + 4 * g;
+                const unsigned char* a0 = ldsV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
+                const unsigned char* a1 = a0 + 16 * 128;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
+            }
+        }
+    }
+    // parallel merge: every wave publishes its state, wave w finishes head dims 16w .. 16w+15
+    f32x4* mine = mbuf + wave * 5 * 64 + lane;
+#pragma unroll
+    for (int td = 0; td < 4; ++td) mine[td * 64] = acc_o[td];
+    mine[4 * 64] = f32x4{m_run, l_run, 0.f, 0.f};
+    __syncthreads();
+    float m_k[4], l_k[4];
+    float m_tot = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 ml = mbuf[(k * 5 + 4) * 64 + lane];
+        m_k[k] = ml[0];
+        l_k[k] = ml[1];
+        m_tot = fmaxf(m_tot, m_k[k]);
+    }
+    float l_tot = 0.f;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = fast_exp2(m_k[k] - m_tot);          // 0 for a wave without keys (m = -inf)
+        l_tot += l_k[k] * wk;
+        const f32x4 ok = mbuf[(k * 5 + wave) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += ok[r] * wk;
+    }
+    const float inv = 1.0f / l_tot;
+    if (q < N) {
+        bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 16 * wave + 4 * g;
+        bf16x4 ob = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst) = ob;
+    }
+}
+
 // ------------------------------------------------------------------------------------ fp32
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int N, int D) {
@@ -309,6 +444,10 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
+    } else if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) &&
+               !getenv("VITVS_ATTN_NO_SHORT")) {
+        dim3 gs((N + 15) / 16, H, n_img);
+        launch(attention_bf16_short_kernel, gs, dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 4 && getenv("VITVS_ATTN_KS4")) {   // experiment switch
         launch(attention_bf16_kernel<4>, grid, dim3(1024), 4 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {

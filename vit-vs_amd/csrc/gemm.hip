@@ -123,12 +123,23 @@ struct EpiPartial {
     }
 };
 
+#ifdef VITVS_PROBE
+// probe builds only (tools/gemm_probe.cpp): per-wave cycle-counter stamps of the kernel's phases
+__device__ unsigned long long* g_gemm_probe;
+#endif
+
 template <typename T, int BM, int BN, int KG, class Epi>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
                                                           int ks_i0) {
     // ks_i0 packs [31:24] K per split-K slice / 32, [23:20] slices, [19:16] tile map, [15:0] i0: one preloaded
     // dword instead of gridDim (hidden kernel arguments the wave would have to fetch) and an integer division.
+#ifdef VITVS_PROBE
+    unsigned long long ts[8];
+    ts[0] = __builtin_readcyclecounter();
+#else
+    unsigned long long* const ts = nullptr;
+#endif
     using Tile = GemmTile<BM, BN, KG>;
     Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -161,7 +172,11 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     float4 col[Tile::NT];
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) col[ni] = epi.column_terms(min(n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4), N - 4));
-    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc);
+    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc, ts);
+#ifdef VITVS_PROBE
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
+    ts[4] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
         if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
@@ -176,7 +191,24 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #endif
         }
     }
+#ifdef VITVS_PROBE
+    ts[5] = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[6] = __builtin_readcyclecounter();
+    if (lane == 0 && g_gemm_probe) {
+        const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        unsigned long long* dst = g_gemm_probe + ((size_t)wg * 8 + (threadIdx.x >> 6)) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = ts[i];
+    }
+#endif
 }
+
+#ifdef VITVS_PROBE
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_gemm_probe(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int k_tile(Precision p) { return (p == PREC_F32) ? 32 : 64; }
 

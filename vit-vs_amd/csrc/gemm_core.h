@@ -87,7 +87,9 @@ template <typename T, int BM, int BN, int KG>
 __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* __restrict__ W, int lda, int ldw,
                                               int m_rows, int n_rows, int m0, int n0, int k_begin, int k_end,
                                               unsigned char* smem,
-                                              f32x4 (&acc)[GemmTile<BM, BN, KG>::NT][GemmTile<BM, BN, KG>::MT]) {
+                                              f32x4 (&acc)[GemmTile<BM, BN, KG>::NT][GemmTile<BM, BN, KG>::MT],
+                                              unsigned long long* ts = nullptr) {
+    // ts: cycle-counter stamps of the phases (probe builds, tools/gemm_probe.cpp); null in production (folded away)
     using Tile = GemmTile<BM, BN, KG>;
     constexpr int EPC = Elem<T>::PER_CHUNK;
     constexpr int BK = 8 * EPC;
@@ -134,6 +136,7 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
     for (int p = 0; p < NST - 1; ++p)
         if (p < nk) issue(p, p);
 
+    if (ts) ts[1] = __builtin_readcyclecounter();
     int stage = 0;                                        // kt % NST
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most min(NST - 2, nk - 1 - kt) younger tiles (L copies each) are outstanding
@@ -144,6 +147,7 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
 #ifndef VITVS_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif
+        if (ts && kt == 0) ts[2] = __builtin_readcyclecounter();
         // every wave has finished reading the stage tile kt - 1 used: refill it with tile kt + NST - 1
         if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
         const unsigned char* sa = ring + stage * Tile::STAGE_BYTES;
@@ -173,6 +177,10 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
                 }
         }
         stage = (stage + 1 == NST) ? 0 : stage + 1;
+    }
+    if (ts) {
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
+        ts[3] = __builtin_readcyclecounter();
     }
     if constexpr (KG == 2) {
         // The two k-groups swap halves through LDS: each group ends up with the full sums of the column
