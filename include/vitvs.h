@@ -17,7 +17,8 @@
  *     the handle owns the device weights and workspaces.  One in-flight call per handle; a handle
  *     is bound to the HIP device that was current when it was created.
  *   - images are RGB uint8, HWC, already resized to img_size x img_size (reference:
- *     vitvs_v2.py:474-475 PIL resize happens before the path; dinov2_extractor.py:177-191).
+ *     vitvs_v2.py:474-475 PIL resize happens before the path; dinov2_extractor.py:177-191);
+ *     vitvs_resize_frames_dev does that resize on the device, bit-identically to PIL.
  *   - depth is the sensor's uint16 millimetre image, 0 = invalid (reference:
  *     realsense_gazebo_plugin/src/RealSensePlugin.cpp:250-262, consumed at vitvs_v2.py:566-586).
  */
@@ -111,6 +112,14 @@ VITVS_API int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const
 VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                            const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status);
+
+/* --- in front of it: camera frame -> extractor input -----------------------------------------------
+ * goal_image.resize((S, S)) / latest_pil_image.resize((S, S)) (vitvs_v2.py:474-475; PIL default filter BICUBIC,
+ * antialiased when shrinking).  frames uint8 [n][in_h][in_w][3] -> out uint8 [n][S][S][3], bit-identical to Pillow's
+ * 8-bit resample (Resample.c).  The first call with a new (in_h, in_w) builds the coefficient tables on the host and
+ * uploads them (one synchronisation); later calls only enqueue one launch. */
+VITVS_API int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t in_h, int32_t in_w,
+                            uint8_t* out, void* stream);
 
 /* --- the seams inside it (same split as the reference's callables) ------------------------------
  * ViTExtractor.extract_descriptors(batch, layer, 'token', bin) (dinov2_extractor.py:313-337):

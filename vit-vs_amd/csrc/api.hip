@@ -63,6 +63,9 @@ struct vitvs_handle {
     bool fused_ln = true, folded = false;
     int desc_keys = -1;   // >= 0 while a velocity update runs: the forward's last launch emits the descriptors and clears this many keys
     bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
+    // Pillow-exact resize tables of the last camera frame size (vitvs_resize_frames_dev)
+    int rs_h = 0, rs_w = 0, rs_ksx = 0, rs_ksy = 0;
+    int *rs_xb = nullptr, *rs_xk = nullptr, *rs_yb = nullptr, *rs_yk = nullptr;
     void* xb = nullptr;       // residual stream in the GEMM operand type (bf16 mode), [M][D]
     float* stats = nullptr;   // per-row partial moments [M][D/16][2]
     // weights
@@ -682,6 +685,34 @@ int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* f
     if (rc) return rc;
     VITVS_HIP_CHECK(hipMemcpyAsync(tokens, h->x, (size_t)n_frames * h->N * h->cfg.dim * sizeof(float),
                                    hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int upload_table(vitvs_handle* h, const std::vector<int>& v, int** dev) {
+    void* p = nullptr;
+    VITVS_HIP_CHECK(hipMalloc(&p, v.size() * sizeof(int)));
+    h->allocs.push_back(p);
+    VITVS_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    *dev = static_cast<int*>(p);
+    return 0;
+}
+
+int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t in_h, int32_t in_w,
+                            uint8_t* out, void* stream) {
+    if (!h || !frames || !out) return set_err(h, -1, "null argument");
+    if (n_frames <= 0 || in_h <= 0 || in_w <= 0) return set_err(h, -5, "bad frame geometry");
+    if (in_h != h->rs_h || in_w != h->rs_w) {   // new camera resolution: build the coefficient tables (synchronises once)
+        std::vector<int> xb, xk, yb, yk;
+        const int ksx = resize_coefficients(in_w, h->cfg.img_size, xb, xk);
+        const int ksy = resize_coefficients(in_h, h->cfg.img_size, yb, yk);
+        if (upload_table(h, xb, &h->rs_xb) || upload_table(h, xk, &h->rs_xk) || upload_table(h, yb, &h->rs_yb) ||
+            upload_table(h, yk, &h->rs_yk))
+            return set_err(h, -6, "resize table upload failed");
+        h->rs_h = in_h; h->rs_w = in_w; h->rs_ksx = ksx; h->rs_ksy = ksy;
+    }
+    const int rc = launch_resize_bicubic(frames, out, n_frames, in_h, in_w, h->cfg.img_size, h->rs_xb, h->rs_xk, h->rs_ksx,
+                                         h->rs_yb, h->rs_yk, h->rs_ksy, as_stream(stream));
+    if (rc) return set_err(h, rc, "resize launch failed");
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // Internal launch interface between the C-ABI layer (api.cpp) and the HIP kernels.
 // All pointers are device pointers; every launch is asynchronous on `stream`.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -169,5 +170,12 @@ struct ServoArgs {
     int max_rows;             // capacity in feature pairs (>= num_pairs; >= T for DENSE)
 };
 int launch_servo(const ServoArgs& a, hipStream_t stream);
+
+// Pillow-exact bicubic resize of n RGB uint8 frames [in_h][in_w][3] -> [out][out][3] (resize.hip).  The tables come from
+// resize_coefficients (host, double precision, Pillow's expressions): bounds [out][2] = (first tap, taps), coefficients
+// [out][ksize] in 22-bit fixed point; x tables for the width, y tables for the height.
+int resize_coefficients(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& coeffs);
+int launch_resize_bicubic(const uint8_t* src, uint8_t* dst, int n, int in_h, int in_w, int out, const int* xb, const int* xk,
+                          int ksx, const int* yb, const int* yk, int ksy, hipStream_t stream);
 
 }  // namespace vitvs

@@ -128,6 +128,22 @@ class Engine:
         self._check(rc, "vitvs_forward_tokens_dev")
         return out
 
+    def resize_frames(self, frames) -> torch.Tensor:
+        """Camera frames uint8 [n,h,w,3] (or [h,w,3]) -> uint8 [n,S,S,3] on the device, bit-identical to
+        ``PIL.Image.resize((S, S))`` (the reference's resize in front of the path, vitvs_v2.py:474-475)."""
+        f = torch.as_tensor(np.ascontiguousarray(frames)) if not torch.is_tensor(frames) else frames
+        if f.dim() == 3:
+            f = f[None]
+        if f.dtype != torch.uint8 or f.dim() != 4 or f.shape[-1] != 3:
+            raise ValueError("frames must be uint8 [n,h,w,3]")
+        f = f.to(self.device).contiguous()
+        n, h, w, _ = f.shape
+        s = self.cfg.img_size
+        out = torch.empty((n, s, s, 3), dtype=torch.uint8, device=self.device)
+        rc = self.lib.vitvs_resize_frames_dev(self.handle, n, _ptr(f), h, w, _ptr(out), _stream_ptr(self.device))
+        self._check(rc, "vitvs_resize_frames_dev")
+        return out
+
     def extract_descriptors(self, frames) -> torch.Tensor:
         """``ViTExtractor.extract_descriptors(..., facet='token', bin=binned)``: [n,1,T,D']."""
         f = self._frames(frames)

@@ -41,8 +41,8 @@ def compute_velocity(engine: Engine, I_cur, I_des, Z, K=None, *, selection="orde
       "dense"      every mutual-NN token
       array-like   explicit token ids of the desired frame
     """
-    v, st = compute_velocity_batch(engine, np.asarray(I_cur)[None], np.asarray(I_des)[None],
-                                   None if Z is None else np.asarray(Z)[None], K, selection=selection,
+    one = lambda a: a[None] if torch.is_tensor(a) else np.asarray(a)[None]   # noqa: E731  (device tensors stay there)
+    v, st = compute_velocity_batch(engine, one(I_cur), one(I_des), None if Z is None else one(Z), K, selection=selection,
                                    generator=generator)
     return v[0], int(st[0])
 
@@ -52,7 +52,7 @@ def compute_velocity_batch(engine: Engine, I_cur, I_des, Z, K=None, *, selection
     """``B`` pairs in one call → (v_c float64 [B,6], status int32 [B]) as numpy arrays."""
     p = engine.params
     K = p.intrinsics() if K is None else K
-    n = np.asarray(I_cur).shape[0]
+    n = int(I_cur.shape[0]) if torch.is_tensor(I_cur) else np.asarray(I_cur).shape[0]
     if isinstance(selection, str) and selection == "reference":
         if n != 1:
             raise ValueError('selection="reference" follows the reference: one pair per call')
@@ -172,14 +172,17 @@ class Controller:
     def image_callback_depth(self, depth_u16):
         self.latest_image_depth = np.asarray(depth_u16)
 
-    def _resized(self, img) -> np.ndarray:
-        """PIL resize to the extractor input (default filter: bicubic), as the reference does before the path."""
-        from PIL import Image
+    def _resized(self, img):
+        """The reference's ``image.resize((S, S))`` (PIL default filter: bicubic, vitvs_v2.py:474-475), done on the
+        device by ``Engine.resize_frames`` — bit-identical to PIL, no host round trip.  Accepts a uint8 HxWx3 array or
+        a PIL image; returns uint8 [S,S,3] (a device tensor when a resize was needed)."""
         s = self.dino_input_size
-        pil = img if hasattr(img, "resize") and not isinstance(img, np.ndarray) else Image.fromarray(np.asarray(img))
-        if pil.size != (s, s):
-            pil = pil.resize((s, s))
-        return np.asarray(pil.convert("RGB"), dtype=np.uint8)
+        if hasattr(img, "convert") and not isinstance(img, np.ndarray):   # PIL image
+            img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        arr = np.asarray(img, dtype=np.uint8)
+        if arr.shape[:2] == (s, s):
+            return arr
+        return self.engine.resize_frames(arr)[0]
 
     # -- the hot path
     def detect_features(self):
@@ -230,8 +233,9 @@ class Controller:
         eng = self.engine
         if eng.max_pairs < len(candidate_frames):
             raise ValueError("engine.max_pairs is smaller than the number of candidates")
-        cur = np.stack([self._resized(f) for f in candidate_frames])
-        des = self._resized(self.goal_image)[None]
+        dev = eng.device
+        cur = torch.stack([torch.as_tensor(self._resized(f)).to(dev) for f in candidate_frames])
+        des = torch.as_tensor(self._resized(self.goal_image)).to(dev)[None]
         z = np.zeros((len(cur), self.params.v_max, self.params.u_max), np.uint16)
         order = torch.stack([torch.randperm(eng.tokens) for _ in range(len(cur))]).to(torch.int32)
         eng.compute_velocity(cur, des, z, self.params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
