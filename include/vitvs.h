@@ -126,6 +126,11 @@ VITVS_API int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const u
  * frames uint8 [n][S][S][3] -> desc fp32 [n][T][D'] (D' = D, or 9D when cfg.binned); raw, un-normalised. */
 VITVS_API int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* desc,
                                   void* stream);
+/* The same call with facet = 'query' | 'key' | 'value' (bin = False, include_cls = False; dinov2_extractor.py:193-217,
+ * 326-334): q / k / v of blocks[layer] for the patch tokens, fp32 [n][T][D] with descriptor index d * H + h.
+ * facet: 0 query, 1 key, 2 value.  In bf16 mode the values carry the qkv GEMM's bf16 output rounding. */
+VITVS_API int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, float* desc,
+                            void* stream);
 /* Residual stream after block `cfg.blocks - 1`, fp32 [n][1+T][D] (what the forward hook captures,
  * dinov2_extractor.py:198-199), for parity tests. */
 VITVS_API int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream);

@@ -119,6 +119,27 @@ def extract_descriptors(sd, frames_u8, *, patch, stride, heads, layer, mean, std
     return x.unsqueeze(1)
 
 
+@torch.no_grad()
+def extract_facet(sd, frames_u8, *, patch, stride, heads, layer, mean, std, facet: str, eps: float = 1e-6) -> torch.Tensor:
+    """``ViTExtractor.extract_descriptors(facet='query'|'key'|'value', bin=False, include_cls=False)``: [B,1,T,D].
+
+    dinov2_extractor.py:193-217: the hook on ``blocks[layer].attn`` recomputes ``qkv = attn.qkv(norm1(x))`` reshaped to
+    [3,B,H,N,hd] and keeps one of the three ([B,H,N,hd]); :326-334 drops the cls token and flattens with
+    ``permute(0,2,3,1)``, i.e. descriptor index = d * H + h (head index fastest)."""
+    idx = {"query": 0, "key": 1, "value": 2}[facet]
+    stages = block_tokens(sd, frames_u8, patch=patch, stride=stride, heads=heads, layer=layer, mean=mean, std=std,
+                          eps=eps, return_all=True)
+    x = stages[layer]                                        # input of blocks[layer]
+    p = f"blocks.{layer}."
+    d = x.shape[-1]
+    y = F.layer_norm(x, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    b, n, c = y.shape
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(b, n, 3, heads, c // heads)
+    f = qkv.permute(2, 0, 3, 1, 4)[idx]                      # B x H x N x hd
+    f = f[:, :, 1:, :]
+    return f.permute(0, 2, 3, 1).flatten(start_dim=-2, end_dim=-1).unsqueeze(1)
+
+
 def log_bin(tokens: torch.Tensor, grid: int) -> torch.Tensor:
     """hierarchy=1 log-binning: for each cell the 3x3 neighbourhood tokens concatenated in
     row-major (dy,dx) order, replicate-clamped at the border (dinov2_extractor.py:289-308).

@@ -406,3 +406,22 @@ def test_controller_failure_counter_raises_like_the_reference():
             ctl.detect_features()
     finally:
         servo.compute_velocity = orig
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("layerscale", [False, True])
+def test_extract_descriptors_facets(precision, tol, layerscale):
+    """query / key / value facets (dinov2_extractor.py:193-217, 326-334): layout d*H + h, cls dropped."""
+    cfg = _tiny_cfg(layerscale)
+    sd = weights.synthetic_state_dict(cfg, 11, affine_jitter=True)
+    eng = _engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision=precision,
+                  max_pairs=1).load_state_dict(sd)
+    frames = np.stack(synth.frame_pair(cfg.img_size, 4242))
+    for facet in ("query", "key", "value"):
+        ref = vit_ref.extract_facet(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                    mean=cfg.mean, std=cfg.std, facet=facet)
+        got = eng.extract_descriptors(frames, facet=facet).cpu()
+        assert got.shape == ref.shape == (2, 1, cfg.tokens, cfg.dim)
+        assert float((got - ref).abs().max() / ref.abs().max()) <= tol
+    with pytest.raises(TypeError):
+        eng.extract_descriptors(frames, facet="attn")

@@ -145,3 +145,31 @@ def test_descriptor_drops_cls_and_bins():
     assert b.shape == (1, 1, cfg.tokens, 9 * cfg.dim)
     centre = b[0, 0, :, 4 * cfg.dim:5 * cfg.dim]
     assert torch.equal(centre, toks[0, 1:])
+
+
+def test_facets_reassemble_the_attention_of_the_hooked_block():
+    """extract_facet's layout (index d*H + h, cls dropped — dinov2_extractor.py:326-334) is pinned by putting q, k, v back
+    together: softmax(q k^T / 8) v through the block's proj must reproduce the attention branch of blocks[layer] for the
+    patch-token queries restricted to patch-token keys... so instead the facets are compared with a direct reshape of
+    qkv(norm1(x)) written the reference's way (reshape(B,N,3,H,hd).permute(2,0,3,1,4))."""
+    import dataclasses
+    import torch.nn.functional as F
+    from vitvs_amd import config, synth, weights
+    cfg = dataclasses.replace(config.vit_config("dino_vits16", 64), dim=128, depth=2, heads=2, layer=1)
+    cfg = dataclasses.replace(cfg, native_grid=cfg.grid)
+    sd = weights.synthetic_state_dict(cfg, 3, affine_jitter=True)
+    frames = np.stack(synth.frame_pair(cfg.img_size, 9))
+    kw = dict(patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+    x_in = vit_ref.block_tokens(sd, frames, return_all=True, **kw)[cfg.layer]
+    p = f"blocks.{cfg.layer}."
+    y = F.layer_norm(x_in, (cfg.dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
+    B, N, C = y.shape
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(B, N, 3, cfg.heads, C // cfg.heads).permute(2, 0, 3, 1, 4)
+    for idx, facet in enumerate(("query", "key", "value")):
+        x = qkv[idx][:, :, 1:, :]                                                    # the reference's hook + cls drop
+        want = x.permute(0, 2, 3, 1).flatten(start_dim=-2, end_dim=-1).unsqueeze(dim=1)   # its flatten, verbatim semantics
+        got = vit_ref.extract_facet(sd, frames, facet=facet, **kw)
+        assert got.shape == (2, 1, cfg.tokens, cfg.dim)
+        assert torch.equal(got, want)
+        h, d = 1, 5                                                                   # spot check of the index rule
+        assert torch.equal(got[0, 0, :, d * cfg.heads + h], qkv[idx][0, h, 1:, d])

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "vitvs_timing_collect": (_I, [_P, _I, _P, _P]),
     "vitvs_tokens": (_I, [_P]),
     "vitvs_desc_dim": (_I, [_P]),
+    "vitvs_extract_facet_dev": (_I, [_P, _I, _P, _I, _P, _P]),
     "vitvs_resize_frames_dev": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "vitvs_op_linear": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_residual": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

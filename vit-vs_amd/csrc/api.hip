@@ -726,6 +726,18 @@ int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8
     return 0;
 }
 
+int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, float* desc,
+                            void* stream) {
+    if (!h || !frames || !desc) return set_err(h, -1, "null argument");
+    if (facet < 0 || facet > 2) return set_err(h, -5, "facet must be 0 (query), 1 (key) or 2 (value)");
+    hipStream_t st = as_stream(stream);
+    int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
+    if (rc) return rc;
+    rc = launch_facet(h->prec, h->qkv, desc, n_frames, h->T, h->cfg.heads, facet, st);
+    if (rc) return set_err(h, rc, "facet launch failed");
+    return 0;
+}
+
 int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* desc1, const float* desc2, int32_t* nn_1,
                          int32_t* nn_2, float* sim_1, float* S_out, void* stream) {
     if (!h || !desc1 || !desc2 || !nn_1 || !nn_2 || !sim_1) return set_err(h, -1, "null argument");

@@ -144,10 +144,21 @@ class Engine:
         self._check(rc, "vitvs_resize_frames_dev")
         return out
 
-    def extract_descriptors(self, frames) -> torch.Tensor:
-        """``ViTExtractor.extract_descriptors(..., facet='token', bin=binned)``: [n,1,T,D']."""
+    def extract_descriptors(self, frames, facet: str = "token") -> torch.Tensor:
+        """``ViTExtractor.extract_descriptors(..., facet, bin=binned)``: [n,1,T,D'].  facet 'token' (the servo
+        path's choice) or 'query' / 'key' / 'value' (un-binned, [n,1,T,D], index d*H + h like the reference)."""
         f = self._frames(frames)
         n = f.shape[0]
+        if facet != "token":
+            if facet not in ("query", "key", "value"):
+                raise TypeError(f"{facet} is not a supported facet.")            # the reference's message
+            if self.binned:
+                raise VitvsError("facets other than 'token' are not binned")
+            out = torch.empty((n, 1, self.tokens, self.cfg.dim), dtype=torch.float32, device=self.device)
+            rc = self.lib.vitvs_extract_facet_dev(self.handle, n, _ptr(f), ("query", "key", "value").index(facet), _ptr(out),
+                                                  _stream_ptr(self.device))
+            self._check(rc, "vitvs_extract_facet_dev")
+            return out
         out = torch.empty((n, 1, self.tokens, self.desc_dim), dtype=torch.float32, device=self.device)
         rc = self.lib.vitvs_extract_descriptors_dev(self.handle, n, _ptr(f), _ptr(out), _stream_ptr(self.device))
         self._check(rc, "vitvs_extract_descriptors_dev")
