@@ -273,11 +273,13 @@ def main():
     symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},64,64,2>:EpiPartial",
               "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
               "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": f"attention_{'bf16' if prec_tag == 'bf16' else 'f32'}_kernel<false>"}.get(dom, dom)
-    traffic = None
+    traffic, mfma_busy = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.isfile(pmc_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1:
         with open(pmc_path) as fh:
-            traffic = json.load(fh).get(symbol, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(fh).get(symbol, {})
+        traffic = pmc.get("hbm_bytes_per_launch")
+        mfma_busy = pmc.get("mfma_busy_cycles_per_launch")
     mfma_bound = dom in ("qkv", "fc1", "attention", "patch_embed", "gram_argmax", "linear_partial(proj+fc2)")
     if mfma_bound:
         peak = PEAK_MFMA["fp32" if dom == "gram_argmax" else args.precision]
@@ -285,6 +287,10 @@ def main():
                     unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic,
                     algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
                     avg_launch_us=round(avg_s * 1e6, 3), event_pair_overhead_us=round(overhead_s * 1e6, 3))
+        if mfma_busy:
+            # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (separate pass, profiles/): busy cycles over the 1024 SIMDs of the chip
+            roof.update(mfma_busy_cycles_per_launch=mfma_busy,
+                        mfma_util_pmc=round(mfma_busy / (1024 * avg_s * 2.4e9), 5))
         if plain and dom == "linear_partial(proj+fc2)":
             # the same kernel in a chain of plain launches (what the un-instrumented step pays per launch)
             p_us = sum(plain[c] * kernels[c]["launches_per_step"] for c in members) / launches

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that refreshes everything under profiles/ for a round (run from the repo root on the GPU box):
-#   bench lines (bf16 with CPU baseline, fp32), rocprofv3 kernel trace + stats, two PMC passes, micro-benchmarks.
+#   bench lines (bf16 with CPU baseline, fp32), rocprofv3 kernel trace + stats, three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES), micro-benchmarks.
 # usage: tools/measure_round.sh r01
 R="${1:-r01}"; O=gpurun_out/$R; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
@@ -10,6 +10,7 @@ for b in 2 4 8; do python bench.py --pairs $b --no-cpu-baseline --steps 100 > $O
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-plain-chain > $GRAFT_REPO_ROOT/$O/bench_bf16_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof_trace.err ) || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_fetch.err ) || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_write -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_write.err ) || exit 1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_mfma -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_mfma.err ) || exit 1
 tools/launch_floor > $O/launch_floor.txt 2>&1
 tools/op_chain > $O/op_chain_bf16.txt 2>&1
 tools/op_chain 32 > $O/op_chain_fp32.txt 2>&1
@@ -18,6 +19,6 @@ find $O -name "*.csv" | head -20
 # keep only the small summaries in the merged output
 python tools/trace_summary.py $(find $O/trace -name "*kernel_trace.csv" | head -1) > $O/trace_summary_bf16.txt
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bf16.csv
-python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) > $O/pmc_traffic.json
-rm -rf $O/trace $O/pmc_fetch $O/pmc_write
+python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $(find $O/pmc_mfma -name "*counter_collection.csv" | head -1) > $O/pmc_traffic.json
+rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 tail -c 600 $O/bench_bf16.json

@@ -283,7 +283,16 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
 
 // Many-row problems (many frame pairs, 448² / 518² inputs): 128x128 tiles halve the LDS and L2 bytes per MFMA.
 static bool big_problem(int M, int N, int splits) {
-    return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= 512;
+    // >= 256 tiles: with 2 workgroups per CU that is one round on every CU or more (measured: 294 tiles -12 %, 176 tiles
+    // +37 % against 64x64 tiles)
+    static const long min_tiles = getenv("VITVS_BIG_MIN_TILES") ? atol(getenv("VITVS_BIG_MIN_TILES")) : 256;   // experiment switch
+    return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= min_tiles;
+}
+
+// Many rows but a narrow layer (N = D: proj, fc2): 128x64 tiles, 48 KB of LDS, three workgroups per CU.
+static bool tall_problem(int M, int N, int splits) {
+    static const long min_tiles = getenv("VITVS_TALL_MIN") ? atol(getenv("VITVS_TALL_MIN")) : 0;   // experiment switch, 0 = off
+    return min_tiles > 0 && splits == 1 && (long)((M + 127) / 128) * (N / 64) >= min_tiles;
 }
 
 template <typename T, class Epi>
@@ -319,6 +328,7 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
                           int splits = 1) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
+    if (tall_problem(M, N, splits)) return launch_one<T, 64, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, true);
     if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
     return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);

@@ -48,10 +48,14 @@ struct GemmTile {
     static constexpr int L = ROWS / 32;                 // LDS-DMA instructions per wave per k-tile
     // ring stages per k-group.  (A 4-stage ring for the two-k-group tiles that fit the 160 KB of LDS
     // was measured 0.7 % SLOWER end to end at one frame pair: profiles/r01_notes.md.)
+    // ring stages per k-group.  One-wave launches (64-row tiles, one workgroup per CU) want tiles in flight: 4 stages, 3
+    // with two k-groups (a 4-stage ring there measured slower).  The 128-row tiles serve many-row problems that run
+    // several waves of workgroups: there occupancy wins — 2 stages = 64 KB (128x128) or 48 KB (128x64), i.e. 2-3
+    // workgroups per CU, measured -24 ... -27 % on the 6274-row fc1 / qkv GEMMs against 4 stages (1 workgroup per CU).
 #ifdef VITVS_LDS_BUDGET   // experiment switch (tools/op_chain): 4 stages wherever the rings fit this many bytes
     static constexpr int NST = (KG * 4 * ROWS * 128 <= VITVS_LDS_BUDGET) ? 4 : 3;
 #else
-    static constexpr int NST = (KG == 1) ? 4 : 3;
+    static constexpr int NST = (BM >= 128) ? 2 : ((KG == 1) ? 4 : 3);
 #endif
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
@@ -118,7 +122,8 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         const bool is_a = g8 * 8 < BM;           // wave-uniform
         base[j] = reinterpret_cast<const unsigned char*>(is_a ? A : W);
         const int r = is_a ? min(m0 + row, m_rows - 1) : min(n0 + row - BM, n_rows - 1);
-        off[j] = ((unsigned)r * (unsigned)(is_a ? lda : ldw) + (unsigned)kg_begin) * (unsigned)sizeof(T) + c * 16;
+        // 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate): rows < 2^24, row pitch in bytes < 2^24
+        off[j] = __umul24((unsigned)r, (unsigned)(is_a ? lda : ldw) * (unsigned)sizeof(T)) + (unsigned)kg_begin * (unsigned)sizeof(T) + c * 16;
     }
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni)
@@ -140,9 +145,9 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
     int stage = 0;                                        // kt % NST
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most min(NST - 2, nk - 1 - kt) younger tiles (L copies each) are outstanding
-        const int younger = nk - 1 - kt;
-        if (NST >= 4 && younger >= 2) wait_vmcnt<2 * L>();
-        else if (younger >= 1) wait_vmcnt<L>();
+        const int younger = min(NST - 2, nk - 1 - kt);
+        if (younger >= 2) wait_vmcnt<2 * L>();
+        else if (younger == 1) wait_vmcnt<L>();
         else wait_vmcnt<0>();
 #ifndef VITVS_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
