@@ -270,7 +270,13 @@ def main():
     avg_s = g_share(dom) / launches * 1e-6
     fl = sum(work[c][0] * kernels[c]["launches_per_step"] for c in members) / launches
     by = sum(work[c][1] * kernels[c]["launches_per_step"] for c in members) / launches
-    symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},64,64,2>:EpiPartial",
+    def narrow_tile(m, n, kk):   # mirror of the tile choice for the N = D layers in csrc/gemm.hip
+        s_ = split_k(m, n, kk, 128 // es)
+        if s_ == 1 and n % 128 == 0 and -(-m // 128) * (n // 128) >= 256:
+            return "128,128,1"
+        tiles = -(-m // 64) * (n // 64) * s_
+        return "64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1"
+    symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},{narrow_tile(2 * B * cfg.seq, cfg.dim, cfg.hidden)}>:EpiPartial",
               "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
               "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": f"attention_{'bf16' if prec_tag == 'bf16' else 'f32'}_kernel<false>"}.get(dom, dom)
     traffic, mfma_busy = None, None
