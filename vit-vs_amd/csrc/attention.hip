@@ -97,33 +97,41 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
                 acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc_s[t4], 0, 0, 0);
             }
         }
+        // softmax on the raw scores: keys beyond N are masked only in the tile that has any (wave-uniform), the
+        // hd^-0.5 * log2(e) scale rides in the exp2 argument's FMA, and the running O^T is rescaled only when some
+        // query's maximum moved (most tiles after the first few leave it alone)
+        if (kb + 64 > N) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb + 16 * t4 + 4 * g + r >= N) acc_s[t4][r] = -INFINITY;
+        }
         float mloc = -INFINITY;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + 16 * t4 + 4 * g + r;
-                float x = acc_s[t4][r] * kScaleLog2e;
-                x = (key < N) ? x : -INFINITY;
-                acc_s[t4][r] = x;
-                mloc = fmaxf(mloc, x);
-            }
-        mloc = rows_max(mloc);
+            for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, acc_s[t4][r]);
+        mloc = rows_max(mloc) * kScaleLog2e;
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
+        const float neg_m = -m_new;
         float psum = 0.f;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(acc_s[t4][r] - m_new);
+                const float p = fast_exp2(__builtin_fmaf(acc_s[t4][r], kScaleLog2e, neg_m));
                 acc_s[t4][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+            for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
 
         // O^T += V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
 #pragma unroll
