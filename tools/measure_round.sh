@@ -4,6 +4,7 @@
 # usage: tools/measure_round.sh r01
 R="${1:-r01}"; O=gpurun_out/$R; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
+make -C tools > /dev/null 2>&1
 python bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err || exit 1
 python bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err || exit 1
 for b in 2 4 8; do python bench.py --pairs $b --no-cpu-baseline --steps 100 > $O/bench_bf16_pairs$b.json 2>/dev/null || exit 1; done
