@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
         bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
 #pragma unroll
         for (int td = 0; td < 4; ++td) {
-            bf16x4 o = {(bf16)(acc_o[td][0] * inv), (bf16)(acc_o[td][1] * inv), (bf16)(acc_o[td][2] * inv),
-                        (bf16)(acc_o[td][3] * inv)};
-            *reinterpret_cast<bf16x4*>(dst + 16 * td) = o;
+            const bf16x4 o = {(bf16)(acc_o[td][0] * inv), (bf16)(acc_o[td][1] * inv), (bf16)(acc_o[td][2] * inv),
+                              (bf16)(acc_o[td][3] * inv)};
+            store_out<(KS >= 2)>(dst + 16 * td, o);   // key-split variants only run on small grids
         }
     }
 }
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
     const float inv = 1.0f / l_tot;
     if (q < N) {
         bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 16 * wave + 4 * g;
-        bf16x4 ob = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
-        *reinterpret_cast<bf16x4*>(dst) = ob;
+        const bf16x4 ob = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+        store_out<true>(dst, ob);
     }
 }
 

@@ -21,6 +21,31 @@ template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; };
 template <> struct Elem<bf16> { static constexpr int PER_CHUNK = 8; };
 
+// Stores of data the NEXT launch consumes.  WT = true gives them the sc1 bit (agent scope: written through to memory
+// as they are issued instead of staying dirty in this XCD's L2 until the end-of-kernel write-back).  In the one-wave
+// (latency-bound) launches that shortens the producer's tail and the consumer's first reads: +4 % updates/s at one
+// frame pair; in the many-row (bandwidth-bound) launches it costs 2-10 %, so those keep plain stores.
+// The 16-byte form has no builtin: inline asm, followed by the two wait states gfx940+ requires between a VMEM store
+// of more than 8 bytes and a VALU write of its data registers (the compiler cannot see into the asm to add them).
+template <bool WT>
+__device__ __forceinline__ void store_out8(void* p, unsigned long long v) {
+    if constexpr (WT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<unsigned long long*>(p) = v;
+}
+template <bool WT>
+__device__ __forceinline__ void store_out16(void* p, u32x4 v) {
+    if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+template <bool WT>
+__device__ __forceinline__ void store_out(float* p, f32x4 v) { store_out16<WT>(p, __builtin_bit_cast(u32x4, v)); }
+template <bool WT>
+__device__ __forceinline__ void store_out(float* p, float4 v) {
+    store_out16<WT>(p, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
+}
+template <bool WT>
+__device__ __forceinline__ void store_out(bf16* p, bf16x4 v) { store_out8<WT>(p, __builtin_bit_cast(unsigned long long, v)); }
+
 // Cross-lane reductions on the VALU (DPP row operations, v_readlane and gfx950's v_permlane{16,32}_swap):
 // the HIP __shfl_* intrinsics go through the LDS crossbar (ds_bpermute, ~100+ cycles of latency per step; a
 // 6-step butterfly is ~0.3 us), which is most of the run time of a one-wave LayerNorm row.

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
     // fetched by the wave and first used after every other load is in flight
     constexpr bool DESC = MODE == RLN_DESC;
     constexpr int D = 4 * NV4 * LANES;
+    const bool wt = M <= 2048;   // few rows: the launch is latency-bound, write-through stores help the consumer (common.h)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x;
     const bool on = lane < LANES;
@@ -237,7 +238,10 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
         if (ls) { acc.x *= ll[i].x; acc.y *= ll[i].y; acc.z *= ll[i].z; acc.w *= ll[i].w; }
         float4 r = v[i];
         r.x += acc.x; r.y += acc.y; r.z += acc.z; r.w += acc.w;
-        if (on) xr[i * LANES + l] = r;
+        if (on) {
+            if (wt) store_out<true>(reinterpret_cast<float*>(xr + i * LANES + l), r);
+            else store_out<false>(reinterpret_cast<float*>(xr + i * LANES + l), r);
+        }
         v[i] = r;
         if (on) s += (r.x + r.y) + (r.z + r.w);
     }
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
             float4* dst = reinterpret_cast<float4*>(desc.dn + ((size_t)img * desc.T + t) * D);
 #pragma unroll
             for (int i = 0; i < NV4; ++i)
-                dst[i * LANES + l] = make_float4(__fdiv_rn(v[i].x, nrm), __fdiv_rn(v[i].y, nrm), __fdiv_rn(v[i].z, nrm),
-                                                 __fdiv_rn(v[i].w, nrm));
+                store_out<true>(reinterpret_cast<float*>(dst + i * LANES + l),
+                                make_float4(__fdiv_rn(v[i].x, nrm), __fdiv_rn(v[i].y, nrm), __fdiv_rn(v[i].z, nrm),
+                                            __fdiv_rn(v[i].w, nrm)));
         }
     }
     if (!gamma) return;
@@ -280,10 +285,12 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
         const float y3 = (v[i].w - mean) * rstd * gg[i].w + be[i].w;
         T* dst = out + (size_t)row * D + 4 * (i * LANES + l);
         if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
+            if (wt) store_out<true>(dst, make_float4(y0, y1, y2, y3));
+            else store_out<false>(dst, make_float4(y0, y1, y2, y3));
         } else {
-            bf16x4 h = {(bf16)y0, (bf16)y1, (bf16)y2, (bf16)y3};
-            *reinterpret_cast<bf16x4*>(dst) = h;
+            const bf16x4 h = {(bf16)y0, (bf16)y1, (bf16)y2, (bf16)y3};
+            if (wt) store_out<true>(dst, h);
+            else store_out<false>(dst, h);
         }
     }
 }

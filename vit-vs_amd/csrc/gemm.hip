@@ -11,24 +11,14 @@
 
 namespace vitvs {
 
-template <typename T>
-__device__ __forceinline__ void store4(T* dst, f32x4 v);
-template <>
-__device__ __forceinline__ void store4<float>(float* dst, f32x4 v) {
-#ifdef VITVS_NT_STORE
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
-#else
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-#endif
-}
-template <>
-__device__ __forceinline__ void store4<bf16>(bf16* dst, f32x4 v) {
-    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-#ifdef VITVS_NT_STORE
-    __builtin_nontemporal_store(h, reinterpret_cast<bf16x4*>(dst));
-#else
-    *reinterpret_cast<bf16x4*>(dst) = h;
-#endif
+template <typename T, bool WT>
+__device__ __forceinline__ void store4(T* dst, f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        store_out<WT>(reinterpret_cast<float*>(dst), v);
+    } else {
+        const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        store_out<WT>(reinterpret_cast<bf16*>(dst), h);
+    }
 }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -56,13 +46,14 @@ struct EpiStore {
         return EpiStore{(T*)out, c0, N, i0};
     }
     __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
+    template <bool WT>
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
-        store4<T>(out + (size_t)m * ldo + n, v);
+        store4<T, WT>(out + (size_t)m * ldo + n, v);
     }
 };
 
@@ -76,7 +67,8 @@ struct EpiResidual {
         return EpiResidual{(float*)out, c0, c1, N};
     }
     __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
+    template <bool WT>
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (ls) {
             const float4 g = *reinterpret_cast<const float4*>(ls + n);
@@ -99,7 +91,8 @@ struct EpiPatch {
         return EpiPatch{(float*)out, c0, c1, i0, N};
     }
     __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4 b) const {
+    template <bool WT>
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
         const int img = m / T, t = m - img * T;
         const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * D + n);
         float4 r = make_float4(v[0] + b.x + pe.x, v[1] + b.y + pe.y, v[2] + b.z + pe.z, v[3] + b.w + pe.w);
@@ -118,8 +111,9 @@ struct EpiPartial {
     }
     __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void set_slice(int z) { part += (size_t)z * M * N; }
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 v, float4) const {
-        store4<float>(part + (size_t)m * N + n, v);
+    template <bool WT>
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4) const {
+        store4<float, WT>(part + (size_t)m * N + n, v);
     }
 };
 
@@ -185,9 +179,9 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
         for (int mi = 0; mi < Tile::MT; ++mi) {
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
 #ifdef VITVS_DBG_NO_EPI
-            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi(m, n, acc[ni][mi], col[ni]);
+            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi.template store<(BM < 128)>(m, n, acc[ni][mi], col[ni]);
 #else
-            if (m < M && n < N) epi(m, n, acc[ni][mi], col[ni]);
+            if (m < M && n < N) epi.template store<(BM < 128)>(m, n, acc[ni][mi], col[ni]);   // 64-row tiles: one-wave launches
 #endif
         }
     }
