@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
                                          : a.cur + (size_t)(img - a.n_des) * a.S * a.S * 3;
     const int pp = a.patch * a.patch;
     T* dst = Ape + (size_t)row * a.Kp;
+    // 4 consecutive k per thread (same channel and patch row when patch % 4 == 0): one 8- or 16-byte write-through store
+    // instead of four 2- or 4-byte stores; the patch-embedding GEMM reads these rows in the next launch
+    if ((a.patch & 3) == 0) {
+        for (int k4 = threadIdx.x * 4; k4 < a.Kp; k4 += blockDim.x * 4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (k4 < 3 * pp) {
+                const int c = k4 / pp, rem = k4 - c * pp;
+                const int py = rem / a.patch, px = rem - py * a.patch;
+                const uint8_t* s = src + ((size_t)(ty * a.stride + py) * a.S + tx * a.stride + px) * 3 + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)s[3 * j], 255.0f), a.mean[c]), a.std[c]);
+            }
+            if constexpr (sizeof(T) == 4) {
+                store_out<true>(reinterpret_cast<float*>(dst + k4), make_float4(v[0], v[1], v[2], v[3]));
+            } else {
+                const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                store_out<true>(reinterpret_cast<bf16*>(dst + k4), h);
+            }
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < a.Kp; k += blockDim.x) {
         float v = 0.f;
         if (k < 3 * pp) {
