@@ -202,14 +202,22 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
 // operand registers, its 64 values into a wave-private LDS slab by LDS-DMA (read back transposed) — and runs the
 // score -> softmax -> PV chain for ONE tile; the four (max, sum, O) states are merged in parallel, wave w
 // finishing head dims 16w .. 16w+15.  No barrier before the merge, a quarter of the 64-query kernel's serial chain.
+// Grid: 1-D, 8 * ceil(items / 8) workgroups, item = (image, head, query block).  Workgroup id i runs on XCD i % 8, and
+// every XCD has its own L2: XCD x takes the x-th eighth of the items in (image, head)-major order, so the K / V slab of
+// an (image, head) — fresh from the qkv launch, i.e. read from memory — is fetched by one XCD (two at a boundary)
+// instead of by all eight.
 __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                                   int N, int D) {
+                                                                   int N, int D, int n_img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = lane & 15, g = lane >> 4;
-    const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
+    const int H = D >> 6, nqb = (N + 15) >> 4, items = n_img * H * nqb, per = (items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= items) return;
+    const int pair = item / nqb;
+    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 16;
     // Addresses: wave-uniform base pointer + 32-bit byte offsets built from 24-bit multiplies (the kernel is a
     // chain of latencies: ~150 instructions of 64-bit address arithmetic before the first request cost 0.4 us).
     const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
@@ -454,8 +462,9 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) &&
                !getenv("VITVS_ATTN_NO_SHORT")) {
-        dim3 gs((N + 15) / 16, H, n_img);
-        launch(attention_bf16_short_kernel, gs, dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, (const bf16*)qkv, (bf16*)out, N, D);
+        const int items = ((N + 15) / 16) * H * n_img;
+        launch(attention_bf16_short_kernel, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream,
+               (const bf16*)qkv, (bf16*)out, N, D, n_img);
     } else if ((long)nt * H * n_img <= 256 && nt >= 4 && getenv("VITVS_ATTN_KS4")) {   // experiment switch
         launch(attention_bf16_kernel<4>, grid, dim3(1024), 4 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
