@@ -29,10 +29,9 @@ __global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const float* __re
     const int kg = (KG == 2) ? k_group() : 0;
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni)
-        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) {
 #pragma unroll
-            for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        }
+        for (int mi = 0; mi < Tile::MT; ++mi)
+            if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) acc[ni][mi] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;

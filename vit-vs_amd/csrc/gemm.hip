@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #endif
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
-        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
         const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
+            if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
 #ifdef VITVS_DBG_NO_EPI
             if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi.template store<(BM < 128)>(m, n, acc[ni][mi], col[ni]);

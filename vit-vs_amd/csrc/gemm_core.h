@@ -62,7 +62,7 @@ struct GemmTile {
     static constexpr int RING_BYTES = KG * GROUP_BYTES;
     // two k-groups swap half of their accumulators through a region of its own (not the rings: no barrier is
     // needed before the swap's writes while other waves still read their last stage)
-    static constexpr int SWAP_SLOTS = ((NT + 1) / 2) * MT;          // accumulator tiles a wave hands over
+    static constexpr int SWAP_SLOTS = (NT * MT + 1) / 2;            // accumulator tiles a wave hands over
     static constexpr int SWAP_BYTES = (KG == 2) ? SWAP_SLOTS * 16 * 512 : 0;
     static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > 160 * 1024;   // no room: reuse the rings (one more barrier)
     static constexpr int SWAP_OFFSET = SWAP_ALIAS ? 0 : RING_BYTES;
@@ -72,9 +72,10 @@ struct GemmTile {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-// With two k-groups, column tile ni of a wave is finished (reduced + epilogue) by this k-group.
-template <int NT>
-__device__ __forceinline__ int tile_owner(int ni) { return (2 * ni >= NT) ? 1 : 0; }
+// With two k-groups, accumulator tile (ni, mi) of a wave is finished (summed + epilogue) by this k-group: the first
+// half of the wave's NT x MT tiles in (ni, mi) order belongs to group 0 (an odd NT, e.g. the 64x96 tile, splits evenly).
+template <int NT, int MT>
+__device__ __forceinline__ int tile_owner(int ni, int mi) { return (2 * (ni * MT + mi) >= NT * MT) ? 1 : 0; }
 __device__ __forceinline__ int k_group() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 8); }
 
 template <int N>
@@ -197,18 +198,16 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         int slot = 0;
 #pragma unroll
         for (int ni = 0; ni < Tile::NT; ++ni)
-            if (tile_owner<Tile::NT>(ni) != kg) {
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) buf[(slot++) * 64] = acc[ni][mi];
-            }
+            for (int mi = 0; mi < Tile::MT; ++mi)
+                if (tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) buf[(slot++) * 64] = acc[ni][mi];
         __syncthreads();
         slot = 0;
 #pragma unroll
         for (int ni = 0; ni < Tile::NT; ++ni)
-            if (tile_owner<Tile::NT>(ni) == kg) {
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] += peer[(slot++) * 64];
-            }
+            for (int mi = 0; mi < Tile::MT; ++mi)
+                if (tile_owner<Tile::NT, Tile::MT>(ni, mi) == kg) acc[ni][mi] += peer[(slot++) * 64];
     }
 }
 

@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256 * KG) void linear_stats_kernel(const T* __restr
     const int kg = (KG == 2) ? k_group() : 0;
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
-        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
         const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
+            if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
             epi.apply(m, n, acc[ni][mi], m < M);
         }
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(256 * KG) void linear_ln_kernel(const T* __restrict
     const int kg = (KG == 2) ? k_group() : 0;
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
-        if (KG == 2 && tile_owner<Tile::NT>(ni) != kg) continue;
         const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
         const float4 c1 = *reinterpret_cast<const float4*>(ln.c1 + n);
         const float4 c2 = *reinterpret_cast<const float4*>(ln.c2 + n);
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
+            if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
             const int ml = wm * Tile::WM + mi * 16 + (lane & 15);
             const int m = m0 + ml;
             const float2 st = rowstat[ml];
