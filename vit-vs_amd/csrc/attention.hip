@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
     unsigned char* ldsK = smem + kgp * (2 * 64 * 128);
     unsigned char* ldsV = ldsK + 64 * 128;
     const int qi = lane & 15, g = lane >> 4;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    lds_u8* vtr = (lds_u8*)ldsV + (4 * g + (qi >> 2)) * 128 + 8 * (qi & 3);   // this lane's corner of a transposed V read
     const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const size_t ld = (size_t)3 * D;
     const bf16* base = qkv + (size_t)img * N * ld + h * 64;
@@ -141,13 +143,11 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
             for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
-                // hardware-transposed LDS read: lane i of the 16-lane group gets column d0+i of 4 key rows
-                const int k0 = 32 * u + 4 * g;
-                const unsigned char* a0 = ldsV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
-                const unsigned char* a1 = a0 + 16 * 128;
+                // hardware-transposed LDS read: lane i of the 16-lane group gets column d0+i of 4 key rows;
+                // one lane-dependent LDS address (vtr), everything else is an immediate offset
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u) * 128 + td * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u + 16) * 128 + td * 32));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
     const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 128u;   // q of this (image, head)
     const unsigned k_off = head_off + 2u * (unsigned)D, v_off = head_off + 4u * (unsigned)D;
     unsigned char* ldsV = smem + wave * 8192;                                  // [64 keys][128 B], this wave's tile
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    lds_u8* vtr = (lds_u8*)ldsV + (4 * g + (qi >> 2)) * 128 + 8 * (qi & 3);   // this lane's corner of a transposed V read
     f32x4* mbuf = reinterpret_cast<f32x4*>(smem + 4 * 8192);                   // [4 waves][5][64 lanes] x 16 B
     const int kb = wave * 64;
     const bool active = kb < N;                                                // wave-uniform
@@ -294,12 +296,9 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
             for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
-                const int k0 = 32 * u + 4 * g;
-                const unsigned char* a0 = ldsV + (k0 + (qi >> 2)) * 128 + (16 * td + 4 * (qi & 3)) * 2;
-                const unsigned char* a1 = a0 + 16 * 128;
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u) * 128 + td * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u + 16) * 128 + td * 32));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
@@ -455,17 +454,19 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
+    static const bool no_short = getenv("VITVS_ATTN_NO_SHORT") != nullptr;   // experiment switches, read once
+    static const bool ks4 = getenv("VITVS_ATTN_KS4") != nullptr;
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) &&
-               !getenv("VITVS_ATTN_NO_SHORT")) {
+               !no_short) {
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_bf16_short_kernel, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream,
                (const bf16*)qkv, (bf16*)out, N, D, n_img);
-    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && getenv("VITVS_ATTN_KS4")) {   // experiment switch
+    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && ks4) {
         launch(attention_bf16_kernel<4>, grid, dim3(1024), 4 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch(attention_bf16_kernel<2>, grid, dim3(512), 2 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);

@@ -295,13 +295,15 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiAr
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
-    if (const char* e = getenv("VITVS_TILE_BN")) {   // experiment switch: force the column-tile width
-        const int bn = atoi(e);
+    static const char* const forced_bn = getenv("VITVS_TILE_BN");   // experiment switch (read once): force the column-tile width
+    static const bool forced_kg2 = getenv("VITVS_TILE_KG2") != nullptr;
+    if (forced_bn) {
+        const int bn = atoi(forced_bn);
         if ((bn == 64 || bn == 96 || bn == 128) && N % bn == 0) {
             pl.bn = bn;
             const long wgs = (long)((M + 63) / 64) * (N / bn);
             pl.kg = (wgs <= 256 && (K / bk) >= 4 && (K / bk) % 2 == 0) ? 2 : 1;
-            if (getenv("VITVS_TILE_KG2") && (K / bk) % 2 == 0) pl.kg = 2;
+            if (forced_kg2 && (K / bk) % 2 == 0) pl.kg = 2;
         }
     }
     if (pl.bn == 128) {
