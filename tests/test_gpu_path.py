@@ -425,3 +425,55 @@ def test_extract_descriptors_facets(precision, tol, layerscale):
         assert float((got - ref).abs().max() / ref.abs().max()) <= tol
     with pytest.raises(TypeError):
         eng.extract_descriptors(frames, facet="attn")
+
+
+# ----------------------------------------------------------------------------------- size-independent properties
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_update_is_bit_reproducible_run_to_run(precision):
+    """The path uses atomicMax on packed (similarity, index) keys and fixed-order split-K sums: two runs of the same
+    update on the headline configuration must agree bit for bit (indices, similarities, v_c)."""
+    cfg = config.baseline_config("vitb16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vitb16_224"])
+    order = torch.randperm(cfg.tokens, generator=torch.Generator().manual_seed(3)).to(torch.int32)[None]
+    runs = []
+    for _ in range(3):
+        v, st = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order)
+        det = eng.last_details(1)
+        runs.append((v.cpu().numpy().copy(), det["nn_1"].copy(), det["nn_2"].copy(), det["sim_1"].copy()))
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert np.array_equal(a, b)
+
+
+def test_swapping_the_frames_swaps_the_nearest_neighbour_tables():
+    """S(cur, des) = S(des, cur)^T: row arg-maxes of one are column arg-maxes of the other (full-size ViT-B/16 pair,
+    fp32; the fixture's margins rule out ties)."""
+    cfg = config.baseline_config("vitb16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vitb16_224"])
+    d = eng.extract_descriptors(np.stack([des, cur]))[:, 0]
+    nn1_a, nn2_a, sim_a = (t.cpu() for t in eng.correspond(d[0], d[1]))
+    nn1_b, nn2_b, sim_b = (t.cpu() for t in eng.correspond(d[1], d[0]))
+    assert torch.equal(nn1_a, nn2_b) and torch.equal(nn2_a, nn1_b)
+    # and sim_1 of the swapped call is the column maximum of the first (dense matrix: another tile shape, so another
+    # summation order of the same fp32 dot products)
+    _, _, _, smat = eng.correspond(d[0], d[1], want_matrix=True)
+    torch.testing.assert_close(sim_b, smat.max(dim=0).values.cpu(), rtol=0, atol=2e-6)
+    assert torch.equal(smat.argmax(dim=0).cpu().to(torch.int32), nn2_a.to(torch.int32))
+
+
+def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
+    """mean(sim_1) > 0.99 (vitvs_v2.py:84-101): identical points on both sides, e = 0, so v_c = 0 exactly."""
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    des, _ = synth.frame_pair(cfg.img_size, 99)
+    v, st = eng.compute_velocity(des, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER,
+                                 selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
+    det = eng.last_details(1)
+    assert int(st[0]) == 0 and int(det["info"][0, 2]) == 1          # same_image flag
+    assert np.array_equal(det["s_uv"][0, :, :2], det["s_uv"][0, :, 2:])
+    assert np.all(v.cpu().numpy() == 0.0)
