@@ -34,7 +34,7 @@ from vitvs_amd import _lib, config, synth, weights  # noqa: E402
 from vitvs_amd import dist as vdist  # noqa: E402
 from vitvs_amd.engine import Engine  # noqa: E402
 
-PEAK_MFMA = {"bf16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
+PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
 
@@ -81,8 +81,8 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     un-instrumented stream (tools/launch_floor.hip), so this is the figure that adds up to `ms_per_step`."""
     import ctypes as C
     lib = _lib.load()
-    code = _lib.BF16 if prec == "bf16" else _lib.F32
-    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32}[prec]
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[prec]
     a = torch.zeros((m, k), dtype=dt, device=dev)
     ws = [torch.zeros((n, k), dtype=dt, device=dev) for _ in range(12)]   # 12 weight sets, like the 12 blocks
     part = torch.zeros((slices, m, n), dtype=torch.float32, device=dev)
@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="vitb16_224", choices=sorted(config.BASELINE_CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,13 +238,13 @@ def main():
         eng.timing_enable(False)
         plain = None
         if rank == 0 and not args.no_plain_chain:
-            m_rows, bk_ = 2 * B * cfg.seq, 128 // (2 if args.precision == "bf16" else 4)
+            m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
             plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
     updates = world * B * args.steps
     value = updates / elapsed
-    es = 2 if args.precision == "bf16" else 4
+    es = 4 if args.precision == "fp32" else 2
     work = kernel_work(cfg, 2 * B, B, es, binned)
     overhead_s = 0.0   # the event pairs are stamped by the dispatch itself (hipExtLaunchKernelGGL): no correction
     kernels = {}
@@ -258,7 +258,7 @@ def main():
                              tflops=round(fl / avg / 1e12, 3), gbps=round(by / avg / 1e9, 1))
     # roofline object: the kernel SYMBOL with the largest share of the step (proj and fc2 are the same
     # split-K kernel, as rocprofv3 --stats reports them), priced with its algorithmic work per launch
-    prec_tag = "bf16" if args.precision == "bf16" else "f32"
+    prec_tag = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision]
     groups = {"linear_partial(proj+fc2)": ["proj", "fc2"]}
     for k in kernels:
         if k not in ("proj", "fc2"):
@@ -278,7 +278,7 @@ def main():
         return "64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1"
     symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},{narrow_tile(2 * B * cfg.seq, cfg.dim, cfg.hidden)}>:EpiPartial",
               "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
-              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": f"attention_{'bf16' if prec_tag == 'bf16' else 'f32'}_kernel<false>"}.get(dom, dom)
+              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": "attention_f32_kernel" if prec_tag == "f32" else f"attention_16_kernel<{prec_tag}>"}.get(dom, dom)
     traffic, mfma_busy = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.isfile(pmc_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1:

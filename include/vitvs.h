@@ -36,7 +36,10 @@ extern "C" {
 
 typedef struct vitvs_handle vitvs_handle;
 
-enum vitvs_precision { VITVS_F32 = 0, VITVS_BF16 = 1 };
+/* operand type of the GEMMs and of attention (accumulation is always fp32, the residual stream, LayerNorm statistics,
+ * descriptors and the correspondence fp32, the control law fp64): F32 = parity mode, BF16 = throughput mode, F16 = the
+ * other 16-bit mode (BASELINE.json configs[4] names fp16; 11-bit significand, same speed as bf16) */
+enum vitvs_precision { VITVS_F32 = 0, VITVS_BF16 = 1, VITVS_F16 = 2 };
 
 /* Servo status (reference error convention):
  *   NO_CORRESPONDENCE  find_correspondences_batch returned (None, None, None)   vitvs_v2.py:155, 500-505

@@ -40,7 +40,9 @@ def _mk(shape, gen, scale=1.0):
     return (torch.randn(shape, generator=gen) * scale).float()
 
 
-PRECS = [("fp32", _lib.F32, torch.float32, F32_TOL), ("bf16", _lib.BF16, torch.bfloat16, BF16_TOL)]
+F16_TOL = 2e-3   # fp16 operands: 11-bit significand, output rounding 2^-11
+PRECS = [("fp32", _lib.F32, torch.float32, F32_TOL), ("bf16", _lib.BF16, torch.bfloat16, BF16_TOL),
+         ("fp16", _lib.F16, torch.float16, F16_TOL)]
 
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
@@ -82,7 +84,7 @@ def test_linear_residual(lib, name, prec, dtype, tol, M, N, K, use_ls):
     rc = lib.vitvs_op_linear_residual(prec, _p(Ad), _p(Wd), _p(bd), _p(lsd), _p(x), M, N, K, _stream())
     assert rc == 0
     torch.cuda.synchronize()
-    assert _rel(x.cpu(), ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)  # bf16: fp32 accumulate, fp32 output
+    assert _rel(x.cpu(), ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)  # 16-bit operands: fp32 accumulate, fp32 output
 
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
@@ -98,7 +100,7 @@ def test_layernorm(lib, name, prec, dtype, tol, M, D):
     rc = lib.vitvs_op_layernorm(prec, _p(xd), _p(gd), _p(bd), _p(out), M, D, 1e-6, _stream())
     assert rc == 0
     torch.cuda.synchronize()
-    assert _rel(out.cpu(), ref) <= (5e-6 if prec == _lib.F32 else 8e-3)
+    assert _rel(out.cpu(), ref) <= {_lib.F32: 5e-6, _lib.BF16: 8e-3, _lib.F16: 1e-3}[prec]
 
 
 def _attention_ref(qkv, n_img, N, H):
@@ -123,7 +125,7 @@ def test_attention(lib, name, prec, dtype, tol, n_img, N, H, scale):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
-    assert _rel(out.cpu(), ref) <= (1e-5 if prec == _lib.F32 else 2e-2)
+    assert _rel(out.cpu(), ref) <= {_lib.F32: 1e-5, _lib.BF16: 2e-2, _lib.F16: 3e-3}[prec]
 
 
 def test_attention_asymmetric_values_catch_transposed_operands(lib):
@@ -136,7 +138,7 @@ def test_attention_asymmetric_values_catch_transposed_operands(lib):
     qkv[:, 64] = torch.where(keys == 77, 40.0, -40.0)  # softmax collapses onto key 77
     qkv[:, 128:192] = keys[:, None] * 0.5 + torch.arange(64, dtype=torch.float32)[None, :] * 0.01
     ref = _attention_ref(qkv, 1, N, H)
-    for prec, dtype, tol in ((_lib.F32, torch.float32, 1e-5), (_lib.BF16, torch.bfloat16, 1e-2)):
+    for prec, dtype, tol in ((_lib.F32, torch.float32, 1e-5), (_lib.BF16, torch.bfloat16, 1e-2), (_lib.F16, torch.float16, 2e-3)):
         q = qkv.to(dtype)
         out = torch.empty((N, 64), dtype=dtype, device="cuda")
         qd = q.cuda()
@@ -144,3 +146,37 @@ def test_attention_asymmetric_values_catch_transposed_operands(lib):
         torch.cuda.synchronize()
         assert _rel(out.cpu(), _attention_ref(q, 1, N, H)) <= tol
     assert float(ref[0, 0]) == pytest.approx(38.5, abs=1e-6)
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,D,K,use_ls,use_ln", [(394, 768, 768, False, True), (394, 768, 3072, True, True),
+                                                  (130, 384, 1536, False, False), (6274, 768, 768, False, True)])
+def test_split_k_pair(lib, name, prec, dtype, tol, M, D, K, use_ls, use_ln):
+    """linear_partial + residual_ln == x + ls * (A W^T + bias), then LayerNorm (the proj / fc2 path of the forward)."""
+    g = torch.Generator().manual_seed(M + D + K)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((D, K), g, K ** -0.5).to(dtype)
+    bias = _mk((D,), g, 0.1)
+    ls = (1.0 + 0.3 * _mk((D,), g)) if use_ls else None
+    gamma, beta = 1.0 + 0.1 * _mk((D,), g), 0.1 * _mk((D,), g)
+    x0 = _mk((M, D), g)
+    upd = A.double() @ W.double().t() + bias.double()
+    if use_ls:
+        upd = upd * ls.double()
+    x_ref = x0.double() + upd
+    y_ref = torch.nn.functional.layer_norm(x_ref, (D,), gamma.double(), beta.double(), 1e-6)
+    slices = lib.vitvs_op_splitk_slices(prec, M, D, K)
+    assert 1 <= slices <= 8
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    lsd = ls.cuda() if use_ls else None
+    gd, bed = gamma.cuda(), beta.cuda()
+    x = x0.clone().cuda()
+    part = torch.full((slices, M, D), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((M, D), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_linear_partial(prec, _p(Ad), _p(Wd), _p(part), M, D, K, slices, _stream()) == 0
+    assert lib.vitvs_op_residual_ln(prec, _p(x), _p(part), slices, _p(bd), _p(lsd), _p(gd) if use_ln else None,
+                                    _p(bed) if use_ln else None, _p(out) if use_ln else None, M, D, 1e-6, _stream()) == 0
+    torch.cuda.synchronize()
+    assert _rel(x.cpu(), x_ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)      # fp32 accumulate, fp32 residual stream
+    if use_ln:
+        assert _rel(out.cpu(), y_ref) <= {_lib.F32: 2e-5, _lib.BF16: 1e-2, _lib.F16: 2e-3}[prec]

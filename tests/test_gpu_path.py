@@ -302,6 +302,33 @@ def test_compute_velocity_bf16_reports_agreement():
     np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-2)
 
 
+def test_compute_velocity_fp16_stays_close_to_the_fp32_oracle():
+    """fp16 operand mode (BASELINE.json configs[4] names fp16): 11-bit significand, so it must sit much closer to the fp32
+    oracle than bf16 does — arg-max agreement and similarities."""
+    case, det, v, st = _e2e("vitb16_224", "plain", "fp16")
+    agree1 = float((det["nn_1"][0] == case["nn_1"]).mean())
+    agree2 = float((det["nn_2"][0] == case["nn_2"]).mean())
+    print(f"fp16 argmax agreement nn_1={agree1:.3f} nn_2={agree2:.3f} v_c rel err={_rel_l2(v, case['v_c']):.3e}")
+    assert st == 0 and np.all(np.isfinite(v))
+    assert agree1 >= 0.97 and agree2 >= 0.97
+    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize("key", ["vitl14_518"])
+def test_forward_tokens_fp16_large_config(key):
+    """DINOv2 ViT-L/14 518² in fp16 (configs[4]): tokens against the fp32 oracle, LayerScale model, resampled grid."""
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    eng = _engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision="fp16",
+                  max_pairs=1).load_state_dict(sd)
+    frame = synth.frame_pair(cfg.img_size, 5)[0][None]
+    got = eng.forward_tokens(frame).cpu()
+    ref = _oracle_tokens(cfg, sd, frame)
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print(f"{key} fp16 tokens: max abs err / max abs = {rel:.3e}")
+    assert torch.isfinite(got).all() and rel <= 1e-2
+
+
 def test_batched_pairs_and_shared_goal():
     """B pairs in one call == B single calls (bit-identical), and des_shared == repeated I_des."""
     cfg = config.baseline_config("vits16_224")

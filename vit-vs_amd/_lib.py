@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VITVS_LIB") or os.path.join(_HERE, "libvitvs_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 1
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 STATUS_OK, STATUS_NO_CORRESPONDENCE, STATUS_TOO_FEW, STATUS_NO_DEPTH = 0, 1, 2, 3
 SELECT_EXPLICIT, SELECT_ORDER, SELECT_DENSE = 0, 1, 2
 

@@ -27,6 +27,15 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     return -100 - (int)e;
 }
 
+static inline Precision to_prec(int32_t p) { return p == VITVS_F32 ? PREC_F32 : (p == VITVS_F16 ? PREC_F16 : PREC_BF16); }
+
+static inline uint16_t f32_to_f16_host(float f) {   // round to nearest even, as the device's v_cvt_f16_f32
+    const _Float16 hval = (_Float16)f;
+    uint16_t bits;
+    memcpy(&bits, &hval, 2);
+    return bits;
+}
+
 static inline uint16_t f32_to_bf16_host(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -151,7 +160,8 @@ int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, si
             memcpy(tmp.data() + r * ld * 4, src + r * cols, cols * 4);
         } else {
             uint16_t* d = reinterpret_cast<uint16_t*>(tmp.data()) + r * ld;
-            for (size_t c = 0; c < cols; ++c) d[c] = f32_to_bf16_host(src[r * cols + c]);
+            if (h->prec == PREC_F16) for (size_t c = 0; c < cols; ++c) d[c] = f32_to_f16_host(src[r * cols + c]);
+            else for (size_t c = 0; c < cols; ++c) d[c] = f32_to_bf16_host(src[r * cols + c]);
         }
     }
     VITVS_HIP_CHECK(hipMemcpy(*dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
@@ -165,7 +175,7 @@ int check_cfg(const vitvs_config* c, std::string& why) {
     if (c->patch <= 0 || c->stride <= 0 || c->img_size < c->patch) { why = "bad patch/stride/img_size"; return -1; }
     if ((c->img_size - c->patch) % c->stride != 0) { why = "img_size - patch must be a multiple of stride"; return -1; }
     if (c->blocks <= 0) { why = "blocks must be >= 1"; return -1; }
-    if (c->precision != VITVS_F32 && c->precision != VITVS_BF16) { why = "unknown precision"; return -1; }
+    if (c->precision != VITVS_F32 && c->precision != VITVS_BF16 && c->precision != VITVS_F16) { why = "unknown precision"; return -1; }
     if (c->max_pairs <= 0 || c->num_pairs <= 0 || c->max_rows < c->num_pairs) { why = "bad capacity"; return -1; }
     if (c->u_max <= 0 || c->v_max <= 0) { why = "bad camera resolution"; return -1; }
     if (c->dim != 128 && c->dim != 256 && c->dim != 384 && c->dim != 768 && c->dim != 1024) {
@@ -480,7 +490,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     if (e != hipSuccess || ndev <= 0) return set_err(nullptr, -2, "no HIP device available");
     vitvs_handle* h = new vitvs_handle();
     h->cfg = *cfg;
-    h->prec = cfg->precision == VITVS_F32 ? PREC_F32 : PREC_BF16;
+    h->prec = to_prec(cfg->precision);
     (void)hipGetDevice(&h->device);
     h->grid = 1 + (cfg->img_size - cfg->patch) / cfg->stride;
     h->T = h->grid * h->grid;
@@ -504,7 +514,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     // and tested, but measured 3-6 % slower at one frame pair (the 84-workgroup fc2 without split-K and the
     // moment merge in the consumers cost more than the two residual_ln launches save) -> opt-in.
     const char* fl = getenv("VITVS_FUSED_LN");
-    h->fused_ln = (fl && fl[0] == '1');
+    h->fused_ln = (fl && fl[0] == '1') && h->prec != PREC_F16;   // the opt-in fused-LayerNorm GEMMs exist for fp32 / bf16
     const char* tc = getenv("VITVS_TWO_CHAINS");
     (void)nc;
     h->two_chains = (tc && tc[0] == '1');
@@ -981,31 +991,31 @@ int vitvs_timing_collect(vitvs_handle* h, int32_t n_classes, double* total_ms, i
 // ---- include/vitvs_ops.h: single-operator entry points for the kernel-level parity tests ----
 int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float* bias, void* out, int32_t M,
                     int32_t N, int32_t K, int32_t gelu, void* stream) {
-    return launch_linear(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, bias, out, M, N, K, gelu, as_stream(stream));
+    return launch_linear(to_prec(precision), A, W, bias, out, M, N, K, gelu, as_stream(stream));
 }
 int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
                              float* x, int32_t M, int32_t N, int32_t K, void* stream) {
-    return launch_linear_residual(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, bias, ls, x, M, N, K, as_stream(stream));
+    return launch_linear_residual(to_prec(precision), A, W, bias, ls, x, M, N, K, as_stream(stream));
 }
 int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
                        int32_t D, float eps, void* stream) {
-    return launch_layernorm(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, x, gamma, beta, out, M, D, eps, as_stream(stream));
+    return launch_layernorm(to_prec(precision), x, gamma, beta, out, M, D, eps, as_stream(stream));
 }
 int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
                        void* stream) {
-    return launch_attention(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, qkv, out, n_img, N, H, as_stream(stream));
+    return launch_attention(to_prec(precision), qkv, out, n_img, N, H, as_stream(stream));
 }
 int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
-    return splitk_slices(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, M, N, K);
+    return splitk_slices(to_prec(precision), M, N, K);
 }
 int vitvs_op_linear_partial(int32_t precision, const void* A, const void* W, float* part, int32_t M, int32_t N,
                             int32_t K, int32_t slices, void* stream) {
-    return launch_linear_partial(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, A, W, part, M, N, K, slices, as_stream(stream));
+    return launch_linear_partial(to_prec(precision), A, W, part, M, N, K, slices, as_stream(stream));
 }
 int vitvs_op_residual_ln(int32_t precision, float* x, const float* part, int32_t slices, const float* bias,
                          const float* ls, const float* gamma, const float* beta, void* out, int32_t M, int32_t D,
                          float eps, void* stream) {
-    return launch_residual_ln(precision == VITVS_F32 ? PREC_F32 : PREC_BF16, x, part, slices, bias, ls, gamma, beta, out, M, D,
+    return launch_residual_ln(to_prec(precision), x, part, slices, bias, ls, gamma, beta, out, M, D,
                               eps, as_stream(stream));
 }
 

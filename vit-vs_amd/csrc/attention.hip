@@ -31,9 +31,11 @@ constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * lo
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
 
 // ------------------------------------------------------------------------------------ bf16
-template <int KS>
-__global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                                  int N, int D) {
+template <typename HT, int KS>
+__global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
+                                                                int N, int D) {
+    typedef typename Vec16<HT>::x8 hx8;
+    typedef typename Vec16<HT>::x4 hx4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = tid >> 6, kgp = wave_all >> 2, wave = wave_all & 3, tl = tid & 255;
@@ -44,16 +46,16 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
     lds_u8* vtr = (lds_u8*)ldsV + (4 * g + (qi >> 2)) * 128 + 8 * (qi & 3);   // this lane's corner of a transposed V read
     const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
     const size_t ld = (size_t)3 * D;
-    const bf16* base = qkv + (size_t)img * N * ld + h * 64;
-    const bf16* Kp = base + D;
-    const bf16* Vp = base + 2 * D;
+    const HT* base = qkv + (size_t)img * N * ld + h * 64;
+    const HT* Kp = base + D;
+    const HT* Vp = base + 2 * D;
 
     const int q = q0 + 16 * wave + qi;
     const int qrow = min(q, N - 1);
-    bf16x8 qf[2];
+    hx8 qf[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-        qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ld + 32 * s + 8 * g));
+        qf[s] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ld + 32 * s + 8 * g));
 
     f32x4 acc_o[4];
 #pragma unroll
@@ -94,9 +96,9 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
             acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
-                acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc_s[t4], 0, 0, 0);
+                const hx8 kf = __builtin_bit_cast(
+                    hx8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
+                acc_s[t4] = mfma16(kf, qf[s], acc_s[t4]);
             }
         }
         // softmax on the raw scores: keys beyond N are masked only in the tile that has any (wave-uniform), the
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
         // O^T += V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8 pf;
+            hx8 pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
+            for (int j = 0; j < 8; ++j) pf[j] = (HT)acc_s[2 * u + (j >> 2)][j & 3];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
                 // hardware-transposed LDS read: lane i of the 16-lane group gets column d0+i of 4 key rows;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u + 16) * 128 + td * 32));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
+                acc_o[td] = mfma16(__builtin_bit_cast(hx8, v8), pf, acc_o[td]);
             }
         }
     }
@@ -186,11 +188,10 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
     l_run = rows_sum(l_run);
     const float inv = 1.0f / l_run;
     if (q < N) {
-        bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
+        HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
 #pragma unroll
         for (int td = 0; td < 4; ++td) {
-            const bf16x4 o = {(bf16)(acc_o[td][0] * inv), (bf16)(acc_o[td][1] * inv), (bf16)(acc_o[td][2] * inv),
-                              (bf16)(acc_o[td][3] * inv)};
+            const hx4 o = {(HT)(acc_o[td][0] * inv), (HT)(acc_o[td][1] * inv), (HT)(acc_o[td][2] * inv), (HT)(acc_o[td][3] * inv)};
             store_out<(KS >= 2)>(dst + 16 * td, o);   // key-split variants only run on small grids
         }
     }
@@ -206,8 +207,11 @@ __global__ __launch_bounds__(256 * KS) void attention_bf16_kernel(const bf16* __
 // every XCD has its own L2: XCD x takes the x-th eighth of the items in (image, head)-major order, so the K / V slab of
 // an (image, head) — fresh from the qkv launch, i.e. read from memory — is fetched by one XCD (two at a boundary)
 // instead of by all eight.
-__global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                                   int N, int D, int n_img) {
+template <typename HT>
+__global__ __launch_bounds__(256) void attention_16_short_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
+                                                                 int N, int D, int n_img) {
+    typedef typename Vec16<HT>::x8 hx8;
+    typedef typename Vec16<HT>::x4 hx4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -232,18 +236,18 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
     const bool active = kb < N;                                                // wave-uniform
     const int q = q0 + qi;
     const unsigned lane_col = 16u * (unsigned)g;
-    bf16x8 qf[2], kf[4][2];
+    hx8 qf[2], kf[4][2];
     {
         const unsigned o = head_off + __umul24((unsigned)min(q, N - 1), row_bytes) + lane_col;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
+        for (int s = 0; s < 2; ++s) qf[s] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
     }
     if (active) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const unsigned o = k_off + __umul24((unsigned)min(kb + 16 * t4 + qi, N - 1), row_bytes) + lane_col;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) kf[t4][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
+            for (int s = 0; s < 2; ++s) kf[t4][s] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(qb + (o + 64u * s)));
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
         for (int t4 = 0; t4 < 4; ++t4) {
             acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc_s[t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t4][s], qf[s], acc_s[t4], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) acc_s[t4] = mfma16(kf[t4][s], qf[s], acc_s[t4]);
         }
         float mloc = -INFINITY;
 #pragma unroll
@@ -291,9 +295,9 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
         // O^T = V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8 pf;
+            hx8 pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (bf16)acc_s[2 * u + (j >> 2)][j & 3];
+            for (int j = 0; j < 8; ++j) pf[j] = (HT)acc_s[2 * u + (j >> 2)][j & 3];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtr + (32 * u + 16) * 128 + td * 32));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc_o[td] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[td], 0, 0, 0);
+                acc_o[td] = mfma16(__builtin_bit_cast(hx8, v8), pf, acc_o[td]);
             }
         }
     }
@@ -332,8 +336,8 @@ __global__ __launch_bounds__(256) void attention_bf16_short_kernel(const bf16* _
     }
     const float inv = 1.0f / l_tot;
     if (q < N) {
-        bf16* dst = out + ((size_t)img * N + q) * D + h * 64 + 16 * wave + 4 * g;
-        const bf16x4 ob = {(bf16)(o[0] * inv), (bf16)(o[1] * inv), (bf16)(o[2] * inv), (bf16)(o[3] * inv)};
+        HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 16 * wave + 4 * g;
+        const hx4 ob = {(HT)(o[0] * inv), (HT)(o[1] * inv), (HT)(o[2] * inv), (HT)(o[3] * inv)};
         store_out<true>(dst, ob);
     }
 }
@@ -452,6 +456,24 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
 }
 
+template <typename HT>
+static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream, bool no_short, bool ks4) {
+    const int D = H * 64;
+    const int nt = (N + 63) / 64;
+    dim3 grid(nt, H, n_img);
+    if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) && !no_short) {
+        const int items = ((N + 15) / 16) * H * n_img;
+        launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
+               out, N, D, n_img);
+    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && ks4) {
+        launch((attention_16_kernel<HT, 4>), grid, dim3(1024), 4 * 2 * 64 * 128, stream, qkv, out, N, D);
+    } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
+        launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
+    } else {
+        launch((attention_16_kernel<HT, 1>), grid, dim3(256), 2 * 64 * 128, stream, qkv, out, N, D);
+    }
+}
+
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
     static const bool no_short = getenv("VITVS_ATTN_NO_SHORT") != nullptr;   // experiment switches, read once
@@ -461,17 +483,10 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
-    } else if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) &&
-               !no_short) {
-        const int items = ((N + 15) / 16) * H * n_img;
-        launch(attention_bf16_short_kernel, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream,
-               (const bf16*)qkv, (bf16*)out, N, D, n_img);
-    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && ks4) {
-        launch(attention_bf16_kernel<4>, grid, dim3(1024), 4 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
-    } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
-        launch(attention_bf16_kernel<2>, grid, dim3(512), 2 * 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
+    } else if (p == PREC_F16) {
+        launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, no_short, ks4);
     } else {
-        launch(attention_bf16_kernel<1>, grid, dim3(256), 2 * 64 * 128, stream, (const bf16*)qkv, (bf16*)out, N, D);
+        launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream, no_short, ks4);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -6,9 +6,12 @@
 namespace vitvs {
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;  // 16-byte register image (native vector: stays in VGPRs)
@@ -20,6 +23,13 @@ constexpr int WAVE = 64;
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; };
 template <> struct Elem<bf16> { static constexpr int PER_CHUNK = 8; };
+template <> struct Elem<f16> { static constexpr int PER_CHUNK = 8; };
+// the two 16-bit operand types share every kernel: vectors of 4 / 8 elements and the f32-accumulating 16x16x32 MFMA
+template <typename H> struct Vec16;
+template <> struct Vec16<bf16> { typedef bf16x4 x4; typedef bf16x8 x8; };
+template <> struct Vec16<f16> { typedef f16x4 x4; typedef f16x8 x8; };
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // Stores of data the NEXT launch consumes.  WT = true gives them the sc1 bit (agent scope: written through to memory
 // as they are issued instead of staying dirty in this XCD's L2 until the end-of-kernel write-back).  In the one-wave
@@ -45,6 +55,8 @@ __device__ __forceinline__ void store_out(float* p, float4 v) {
 }
 template <bool WT>
 __device__ __forceinline__ void store_out(bf16* p, bf16x4 v) { store_out8<WT>(p, __builtin_bit_cast(unsigned long long, v)); }
+template <bool WT>
+__device__ __forceinline__ void store_out(f16* p, f16x4 v) { store_out8<WT>(p, __builtin_bit_cast(unsigned long long, v)); }
 
 // Cross-lane reductions on the VALU (DPP row operations, v_readlane and gfx950's v_permlane{16,32}_swap):
 // the HIP __shfl_* intrinsics go through the LDS crossbar (ds_bpermute, ~100+ cycles of latency per step; a
@@ -169,9 +181,11 @@ __device__ __forceinline__ int tile256_off(int row, int chunk) {
 template <typename T> __device__ __forceinline__ T from_float(float v);
 template <> __device__ __forceinline__ float from_float<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_float<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_float<f16>(float v) { return (f16)v; }
 
 __device__ __forceinline__ float to_float(float v) { return v; }
 __device__ __forceinline__ float to_float(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_float(f16 v) { return (float)v; }
 
 // total order on floats as unsigned keys (larger float -> larger key)
 __device__ __forceinline__ unsigned ordered_key(float f) {

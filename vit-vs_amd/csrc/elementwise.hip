@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
             if constexpr (sizeof(T) == 4) {
                 store_out<true>(reinterpret_cast<float*>(dst + k4), make_float4(v[0], v[1], v[2], v[3]));
             } else {
-                const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                store_out<true>(reinterpret_cast<bf16*>(dst + k4), h);
+                const typename Vec16<T>::x4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+                store_out<true>(dst + k4, h);
             }
         }
         return;
@@ -91,6 +91,8 @@ int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hip
     if (rows <= 0 || a.Kp < 3 * a.patch * a.patch) return -2;
     if (p == PREC_F32)
         launch(patchify_kernel<float>, dim3(rows), dim3(256), 0, stream, a, (float*)Ape, x);
+    else if (p == PREC_F16)
+        launch(patchify_kernel<f16>, dim3(rows), dim3(256), 0, stream, a, (f16*)Ape, x);
     else
         launch(patchify_kernel<bf16>, dim3(rows), dim3(256), 0, stream, a, (bf16*)Ape, x);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -134,9 +136,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if constexpr (sizeof(T) == 4) {
             *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
         } else {
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-            bf16x2 h = {(bf16)y0, (bf16)y1};
-            *reinterpret_cast<bf16x2*>(dst) = h;
+            typedef T t16x2 __attribute__((ext_vector_type(2)));
+            const t16x2 h = {(T)y0, (T)y1};
+            *reinterpret_cast<t16x2*>(dst) = h;
         }
     }
 }
@@ -160,6 +162,7 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
                      float eps, hipStream_t stream) {
     if (M <= 0) return -2;
     if (p == PREC_F32) return launch_ln_t<float>(x, gamma, beta, (float*)out, M, D, eps, stream);
+    if (p == PREC_F16) return launch_ln_t<f16>(x, gamma, beta, (f16*)out, M, D, eps, stream);
     return launch_ln_t<bf16>(x, gamma, beta, (bf16*)out, M, D, eps, stream);
 }
 
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
             if (wt) store_out<true>(dst, make_float4(y0, y1, y2, y3));
             else store_out<false>(dst, make_float4(y0, y1, y2, y3));
         } else {
-            const bf16x4 h = {(bf16)y0, (bf16)y1, (bf16)y2, (bf16)y3};
+            const typename Vec16<T>::x4 h = {(T)y0, (T)y1, (T)y2, (T)y3};
             if (wt) store_out<true>(dst, h);
             else store_out<false>(dst, h);
         }
@@ -345,6 +348,7 @@ static int launch_rln_p(Precision p, float* x, const float* part, int splits, co
                         const float* g, const float* b, void* out, int M, int D, float eps, hipStream_t stream,
                         const RlnExtra& ex) {
     if (p == PREC_F32) return launch_rln_t<float, MODE>(x, part, splits, bias, ls, g, b, (float*)out, M, D, eps, stream, ex);
+    if (p == PREC_F16) return launch_rln_t<f16, MODE>(x, part, splits, bias, ls, g, b, (f16*)out, M, D, eps, stream, ex);
     return launch_rln_t<bf16, MODE>(x, part, splits, bias, ls, g, b, (bf16*)out, M, D, eps, stream, ex);
 }
 
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(256) void facet_kernel(const T* __restrict__ qkv, f
 int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, hipStream_t stream) {
     if (n_img <= 0 || T <= 0 || H <= 0 || which < 0 || which > 2) return -2;
     if (p == PREC_F32) launch(facet_kernel<float>, dim3(n_img * T), dim3(256), 0, stream, (const float*)qkv, out, T, H, which);
+    else if (p == PREC_F16) launch(facet_kernel<f16>, dim3(n_img * T), dim3(256), 0, stream, (const f16*)qkv, out, T, H, which);
     else launch(facet_kernel<bf16>, dim3(n_img * T), dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

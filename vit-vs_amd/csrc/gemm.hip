@@ -16,8 +16,8 @@ __device__ __forceinline__ void store4(T* dst, f32x4 v) {
     if constexpr (sizeof(T) == 4) {
         store_out<WT>(reinterpret_cast<float*>(dst), v);
     } else {
-        const bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        store_out<WT>(reinterpret_cast<bf16*>(dst), h);
+        const typename Vec16<T>::x4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        store_out<WT>(dst, h);
     }
 }
 
@@ -335,6 +335,7 @@ int launch_linear(Precision p, const void* A, const void* W, const float* bias, 
     if (!shapes_ok(p, M, N, K)) return -2;
     const EpiArgs e{out, bias, nullptr, gelu};
     if (p == PREC_F32) return launch_tiles<float, EpiStore<float>>((const float*)A, (const float*)W, M, N, K, e, stream);
+    if (p == PREC_F16) return launch_tiles<f16, EpiStore<f16>>((const f16*)A, (const f16*)W, M, N, K, e, stream);
     return launch_tiles<bf16, EpiStore<bf16>>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
@@ -343,6 +344,7 @@ int launch_linear_residual(Precision p, const void* A, const void* W, const floa
     if (!shapes_ok(p, M, N, K)) return -2;
     const EpiArgs e{x, bias, ls, 0};
     if (p == PREC_F32) return launch_tiles64<float, EpiResidual>((const float*)A, (const float*)W, M, N, K, e, stream);
+    if (p == PREC_F16) return launch_tiles64<f16, EpiResidual>((const f16*)A, (const f16*)W, M, N, K, e, stream);
     return launch_tiles64<bf16, EpiResidual>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
@@ -364,6 +366,7 @@ int launch_linear_partial(Precision p, const void* A, const void* W, float* part
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
     const EpiArgs e{part, nullptr, nullptr, 0};
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
+    if (p == PREC_F16) return launch_tiles64<f16, EpiPartial>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
     return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 
@@ -373,6 +376,7 @@ int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const floa
     if (!shapes_ok(p, M, D, Kp)) return -2;
     const EpiArgs e{x, bias, pos, T};
     if (p == PREC_F32) return launch_tiles64<float, EpiPatch>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
+    if (p == PREC_F16) return launch_tiles64<f16, EpiPatch>((const f16*)Ape, (const f16*)Wpe, M, D, Kp, e, stream);
     return launch_tiles64<bf16, EpiPatch>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);
 }
 

@@ -17,7 +17,7 @@
 // ends up holding 4 consecutive n for one m (16-byte epilogue accesses).
 //
 //   f32 : v_mfma_f32_16x16x4_f32   (exact fp32 FMA chain, 4 per 16-byte chunk pair)
-//   bf16: v_mfma_f32_16x16x32_bf16 (one per 16-byte chunk pair), fp32 accumulate
+//   bf16: v_mfma_f32_16x16x32_bf16 (one per 16-byte chunk pair), fp32 accumulate; fp16: v_mfma_f32_16x16x32_f16, the same
 #pragma once
 #include "common.h"
 
@@ -33,6 +33,10 @@ __device__ __forceinline__ f32x4 mma_chunk<float>(f32x4 acc, u32x4 a, u32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[2]), __uint_as_float(b[2]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[3]), __uint_as_float(b[3]), acc, 0, 0, 0);
     return acc;
+}
+template <>
+__device__ __forceinline__ f32x4 mma_chunk<f16>(f32x4 acc, u32x4 a, u32x4 b) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ f32x4 mma_chunk<bf16>(f32x4 acc, u32x4 a, u32x4 b) {

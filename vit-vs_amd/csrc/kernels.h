@@ -35,7 +35,7 @@ inline void launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stre
     }
 }
 
-enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1 };
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };   // operand type of the GEMMs / attention; fp32 accumulate
 
 inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
 

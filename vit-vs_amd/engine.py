@@ -39,8 +39,8 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self.params = params or ServoParams(dino_input_size=cfg.img_size)
-        self.precision = {"fp32": _lib.F32, "f32": _lib.F32, "bf16": _lib.BF16}[precision]
-        self.precision_name = "fp32" if self.precision == _lib.F32 else "bf16"
+        self.precision = {"fp32": _lib.F32, "f32": _lib.F32, "bf16": _lib.BF16, "fp16": _lib.F16, "f16": _lib.F16}[precision]
+        self.precision_name = {_lib.F32: "fp32", _lib.BF16: "bf16", _lib.F16: "fp16"}[self.precision]
         self.binned = self.params.use_feature_binning if binned is None else bool(binned)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_pairs = int(max_pairs)
