@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="vitb16_224", choices=sorted(config.BASELINE_CONFIGS))
+    ap.add_argument("--selection", default="order", choices=["order", "dense"],
+                    help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plain-chain", action="store_true",
                     help="skip the plain-launch chain of the dominant GEMM (profiler runs: keeps the kernel trace to the steps)")
@@ -169,7 +171,8 @@ def main():
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=binned)
     sd = weights.synthetic_state_dict(cfg, 0)
     B = args.pairs
-    eng = Engine(cfg, params, precision=args.precision, max_pairs=B).load_state_dict(sd)
+    dense = args.selection == "dense"
+    eng = Engine(cfg, params, precision=args.precision, max_pairs=B, max_rows=cfg.tokens if dense else None).load_state_dict(sd)
 
     # per-rank synthetic inputs, resident in HBM
     seed0 = synth.ACCEPTED_FRAME_SEEDS[args.config]
@@ -194,7 +197,10 @@ def main():
 
     def step(i):
         # a fresh visiting order per update, already resident (launches are eager, so the pointer may change)
-        eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i], None, False, v, status)
+        if dense:
+            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, v, status)
+        else:
+            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i], None, False, v, status)
         if world > 1:
             vdist.gather_velocities(v, world * B, out=v_all)
 
@@ -317,7 +323,7 @@ def main():
                              f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update",
                     key=args.config, pairs_per_step_per_gpu=B, tokens=cfg.tokens, dim=cfg.dim,
                     parallelism=f"dp{world} (frame pairs sharded, v_c all-gather per step)" if world > 1 else "single GPU",
-                    weights="synthetic seed 0", selection="ORDER"),
+                    weights="synthetic seed 0", selection="DENSE" if dense else "ORDER"),
         roofline=roof,
         cpu_baseline=None,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),

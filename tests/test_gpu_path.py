@@ -504,3 +504,32 @@ def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
     assert int(st[0]) == 0 and int(det["info"][0, 2]) == 1          # same_image flag
     assert np.array_equal(det["s_uv"][0, :, :2], det["s_uv"][0, :, 2:])
     assert np.all(v.cpu().numpy() == 0.0)
+
+
+def test_dense_correspondence_and_interaction_matrix_at_3136_tokens():
+    """BASELINE configs[2]: DINO ViT-B/8 448² — every mutual nearest neighbour of the 3136 tokens enters L_e (thousands of
+    rows: the interaction matrix lives in the global workspace and the pseudo-inverse runs as one-sided Jacobi SVD).
+    The law is checked against the oracle GIVEN the device's own nearest-neighbour tables (their parity with the oracle's
+    similarity matrix is test_compute_velocity_fp32_many_tokens)."""
+    key = "vitb8_448"
+    cfg = config.baseline_config(key)
+    blob = load_golden(f"e2e_{key}.npz")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
+    depth = synth.depth_pattern()
+    v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    det = eng.last_details(1)
+    nn1, nn2 = det["nn_1"][0].astype(np.int64), det["nn_2"][0].astype(np.int64)
+    g = cfg.grid
+    mutual = np.nonzero(nn2[nn1] == np.arange(cfg.tokens))[0]
+    assert int(st[0]) == 0 and len(mutual) > 128                       # more rows than the on-chip L_e holds
+    assert int(det["info"][0, 1]) == len(mutual) and det["selected"][0, :len(mutual)].tolist() == mutual.tolist()
+    p1 = torch.from_numpy(np.stack([mutual // g, mutual % g], 1))
+    p2 = torch.from_numpy(np.stack([nn1[mutual] // g, nn1[mutual] % g], 1))
+    s_star, s = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), len(mutual),
+                                params.u_max, params.v_max, cfg.img_size)
+    ref = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+    assert np.array_equal(det["s_uv"][0, :len(mutual), :2], np.asarray(s_star)) and np.array_equal(det["s_uv"][0, :len(mutual), 2:], np.asarray(s))
+    assert _rel_l2(v.cpu().numpy()[0], ref["v_c"]) <= 1e-9

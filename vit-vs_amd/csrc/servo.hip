@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void servo_kernel(const unsigned long long* __
     if (!depth) status = ST_NO_DEPTH;
     else if (none) status = ST_NO_CORRESPONDENCE;
     else if (too_few) status = ST_TOO_FEW;
-    const bool try_fast = status == ST_OK && R > 0 && use_lds;
+    const bool try_fast = status == ST_OK && R > 0;   // L in LDS or (dense selections) in the global workspace
     if (try_fast) {
         // 27 quantities x 8 row slices on 216 threads (fixed slice order -> deterministic)
         const int qid = tid & 31, slice = tid >> 5;
@@ -255,9 +255,16 @@ __global__ __launch_bounds__(256) void servo_kernel(const unsigned long long* __
                 ca = qid - 21;
                 cb = 6;
             }
-            double acc = 0.0;
-            for (int r = slice; r < R; r += 8) acc += Lc[ca * rcap + r] * Lc[cb * rcap + r];
-            Gs[40 + slice * 27 + qid] = acc;
+            // 4 independent chains keep 8 loads in flight (dense selections read L from the global workspace);
+            // fixed combination order -> still deterministic
+            double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+            int r = slice;
+            for (; r + 24 < R; r += 32) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc4[u] += Lc[ca * rcap + r + 8 * u] * Lc[cb * rcap + r + 8 * u];
+            }
+            for (; r < R; r += 8) acc4[0] += Lc[ca * rcap + r] * Lc[cb * rcap + r];
+            Gs[40 + slice * 27 + qid] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         }
         lds_barrier();
     }
