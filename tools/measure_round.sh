@@ -8,6 +8,11 @@ make -C tools > /dev/null 2>&1
 python bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err || exit 1
 python bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err || exit 1
 for b in 2 4 8; do python bench.py --pairs $b --no-cpu-baseline --steps 100 > $O/bench_bf16_pairs$b.json 2>/dev/null || exit 1; done
+python bench.py --precision fp16 --no-cpu-baseline > $O/bench_fp16.json 2>/dev/null || exit 1
+# the other BASELINE.json configurations (parity-test cases; not the headline)
+for c in vitb8_448 vitl14_518 vits14_308 vits16_224; do python bench.py --config $c --steps 50 --warmup 5 --no-cpu-baseline --no-plain-chain > $O/bench_bf16_$c.json 2>/dev/null || exit 1; done
+python bench.py --config vitb8_448 --selection dense --steps 50 --warmup 5 --no-cpu-baseline --no-plain-chain > $O/bench_bf16_vitb8_448_dense.json 2>/dev/null || exit 1
+python bench.py --config vitl14_518 --precision fp16 --steps 50 --warmup 5 --no-cpu-baseline --no-plain-chain > $O/bench_fp16_vitl14_518.json 2>/dev/null || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-plain-chain > $GRAFT_REPO_ROOT/$O/bench_bf16_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof_trace.err ) || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_fetch.err ) || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_write -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_write.err ) || exit 1
