@@ -356,56 +356,38 @@ ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
 int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part,
                   hipStream_t st) {
     const vitvs_config& c = h->cfg;
-    const int M = cnt * h->N, D = c.dim;
-    const size_t es = elem_size(h->prec);
-    const size_t img_bytes = (size_t)c.img_size * c.img_size * 3;
-    const size_t row0 = (size_t)i0 * h->N;
-    float* x = h->x + row0 * D;
-    unsigned char* xn = (unsigned char*)h->xn + row0 * D * es;
-    unsigned char* qkv = (unsigned char*)h->qkv + row0 * 3 * D * es;
-    unsigned char* attn = (unsigned char*)h->attn + row0 * D * es;
-    unsigned char* hid = (unsigned char*)h->hid + row0 * h->hidden * es;
-    unsigned char* Ape = (unsigned char*)h->Ape + (size_t)i0 * h->T * h->Kp * es;
-    PatchifyArgs pa;
-    pa.n_des = std::max(0, std::min(i0 + cnt, n_des) - i0);
-    pa.n_cur = cnt - pa.n_des;
-    pa.des = des ? des + (size_t)std::min(i0, n_des) * img_bytes : nullptr;
-    pa.cur = cur ? cur + (size_t)std::max(i0 - n_des, 0) * img_bytes : nullptr;
-    pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
-    for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
-    pa.cls = h->cls; pa.pos = h->pos;
-    pa.xb = nullptr; pa.stats = nullptr;
-    int rc;
+    ChainCtx cx = fill_ctx(h, i0, cnt, n_des, des, cur, part);
     if (h->fused_ln) {
-        // 5 launches per block: the LayerNorms live in the GEMM epilogues (gemm_fused.hip)
-        unsigned char* xb = (h->prec == PREC_BF16) ? (unsigned char*)h->xb + row0 * D * es : nullptr;
+        // opt-in: 5 launches per block, the LayerNorms live in the GEMM epilogues (gemm_fused.hip)
+        const int M = cx.M, D = c.dim;
+        const size_t row0 = (size_t)i0 * h->N;
+        unsigned char* xb = (h->prec == PREC_BF16) ? (unsigned char*)h->xb + row0 * D * elem_size(h->prec) : nullptr;
         float* stats = h->stats + row0 * (D / 16) * 2;
-        const void* a_op = xb ? (const void*)xb : (const void*)x;   // operand of the qkv / fc1 GEMMs
-        pa.xb = xb; pa.stats = stats;
-        { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, pa, Ape, x, st); }
+        const void* a_op = xb ? (const void*)xb : (const void*)cx.x;   // operand of the qkv / fc1 GEMMs
+        cx.pa.xb = xb; cx.pa.stats = stats;
+        int rc;
+        { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, cx.pa, cx.Ape, cx.x, st); }
         if (rc) return set_err(h, rc, "patchify launch failed");
         { Span sp(h, KC_PATCH_EMBED, st);
-          rc = launch_patch_embed_stats(h->prec, Ape, h->pe_w, h->pe_b, h->pos, x, xb, stats, cnt, h->T, D, h->Kp, st); }
+          rc = launch_patch_embed_stats(h->prec, cx.Ape, h->pe_w, h->pe_b, h->pos, cx.x, xb, stats, cnt, h->T, D, h->Kp, st); }
         if (rc) return set_err(h, rc, "patch-embed launch failed");
         for (int i = 0; i < c.blocks; ++i) {
             const Block& b = h->blk[i];
             { Span sp(h, KC_QKV, st);
-              rc = launch_linear_ln(h->prec, a_op, b.qkvw_f, b.qkv_c1, b.qkv_c2, stats, D, qkv, M, 3 * D, D, 0, c.ln_eps, st); }
-            if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, qkv, attn, cnt, h->N, c.heads, st); }
+              rc = launch_linear_ln(h->prec, a_op, b.qkvw_f, b.qkv_c1, b.qkv_c2, stats, D, cx.qkv, M, 3 * D, D, 0, c.ln_eps, st); }
+            if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, cx.qkv, cx.attn, cnt, h->N, c.heads, st); }
             if (!rc) { Span sp(h, KC_PROJ, st);
-                       rc = launch_linear_residual_stats(h->prec, attn, b.projw, b.projb, b.ls1, x, xb, stats, M, D, D, st); }
+                       rc = launch_linear_residual_stats(h->prec, cx.attn, b.projw, b.projb, b.ls1, cx.x, xb, stats, M, D, D, st); }
             if (!rc) { Span sp(h, KC_FC1, st);
-                       rc = launch_linear_ln(h->prec, a_op, b.fc1w_f, b.fc1_c1, b.fc1_c2, stats, D, hid, M, h->hidden, D, 1,
+                       rc = launch_linear_ln(h->prec, a_op, b.fc1w_f, b.fc1_c1, b.fc1_c2, stats, D, cx.hid, M, h->hidden, D, 1,
                                              c.ln_eps, st); }
             if (!rc) { Span sp(h, KC_FC2, st);
-                       rc = launch_linear_residual_stats(h->prec, hid, b.fc2w, b.fc2b, b.ls2, x, xb, stats, M, D, h->hidden, st); }
+                       rc = launch_linear_residual_stats(h->prec, cx.hid, b.fc2w, b.fc2b, b.ls2, cx.x, xb, stats, M, D, h->hidden,
+                                                         st); }
             if (rc) return set_err(h, rc, "block launch failed");
         }
         return 0;
     }
-    ChainCtx cx;
-    cx.cnt = cnt; cx.M = M; cx.x = x; cx.xn = xn; cx.qkv = qkv; cx.attn = attn; cx.hid = hid; cx.Ape = Ape; cx.part = part;
-    cx.pa = pa;
     if (h->desc_keys >= 0 && desc_in_forward(h)) {
         cx.want_desc = true;
         cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
@@ -712,6 +694,14 @@ int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* fr
     if (!h || !frames || !out) return set_err(h, -1, "null argument");
     if (n_frames <= 0 || in_h <= 0 || in_w <= 0) return set_err(h, -5, "bad frame geometry");
     if (in_h != h->rs_h || in_w != h->rs_w) {   // new camera resolution: build the coefficient tables (synchronises once)
+        for (int** t : {&h->rs_xb, &h->rs_xk, &h->rs_yb, &h->rs_yk}) {   // drop the previous resolution's tables
+            if (*t) {
+                VITVS_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+                h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*t), h->allocs.end());
+                (void)hipFree(*t);
+                *t = nullptr;
+            }
+        }
         std::vector<int> xb, xk, yb, yk;
         const int ksx = resize_coefficients(in_w, h->cfg.img_size, xb, xk);
         const int ksy = resize_coefficients(in_h, h->cfg.img_size, yb, yk);
