@@ -243,7 +243,7 @@ def main():
         prof = eng.timing_collect()
         eng.timing_enable(False)
         plain = None
-        if rank == 0 and not args.no_plain_chain:
+        if rank == 0 and world == 1 and not args.no_plain_chain:   # single-process extra; ranks stay in lock step at N > 1
             m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
             plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
