@@ -60,3 +60,20 @@ def test_engine_fails_loudly_without_gpu():
     from vitvs_amd.engine import Engine, VitvsError
     with pytest.raises(VitvsError):
         Engine(config.baseline_config("vits16_224"))
+
+
+def test_bench_split_k_mirror_matches_the_library_plan():
+    """bench.py prices the split-K GEMM with its own mirror of the slice plan; the plan itself is host arithmetic in the
+    library (no device call), so the two can be compared without a GPU."""
+    import importlib.util
+    import os
+    from vitvs_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib = _lib.load()
+    for prec, bk in ((_lib.BF16, 64), (_lib.F16, 64), (_lib.F32, 32)):
+        for m in (197, 394, 788, 1576, 3152, 970, 2740, 6274):
+            for n, k in ((768, 768), (768, 3072), (384, 384), (384, 1536), (1024, 1024), (1024, 4096), (768, 640), (768, 192)):
+                assert bench.split_k(m, n, k, bk) == lib.vitvs_op_splitk_slices(prec, m, n, k), (prec, m, n, k)
