@@ -157,7 +157,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # VITVS_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, per-update all-gather) in a world of one rank —
+    # the only way to exercise the RCCL path on a one-GPU box
+    multi = world > 1 or os.environ.get("VITVS_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VITVS_DIST_BACKEND", "nccl")
@@ -191,22 +194,35 @@ def main():
     order_buf = torch.empty((B, cfg.tokens), dtype=torch.int32, device=dev)
     v = torch.zeros((B, 6), dtype=torch.float64, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
-    v_all = torch.zeros((world * B, 6), dtype=torch.float64, device=dev) if world > 1 else None
+    v_all = torch.zeros((world * B, 6), dtype=torch.float64, device=dev) if multi else None
+    # N > 1: one synchronous v_c all-gather per update (torch.distributed on RCCL).  VITVS_ASYNC_GATHER=1 issues it
+    # asynchronously on RCCL's own stream with alternating buffers (vit-vs_amd/dist.py: VelocityGather) — measured on one
+    # GPU in a world of one rank that is SLOWER (0.577 vs 0.464 ms per update; no gather: 0.449): work of two queues
+    # alternates on this platform instead of overlapping, so the second queue costs more than the wait it removes.
+    async_gather = (multi and os.environ.get("VITVS_DIST_BACKEND", "nccl") == "nccl"
+                    and os.environ.get("VITVS_ASYNC_GATHER") == "1")
+    gather = vdist.VelocityGather(world * B, dev) if async_gather else None
+    v_slots = [v, torch.zeros_like(v)]
 
     stream = torch.cuda.Stream(device=dev)
 
     def step(i):
         # a fresh visiting order per update, already resident (launches are eager, so the pointer may change)
+        vi = v_slots[i & 1] if async_gather else v
         if dense:
-            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, v, status)
+            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, vi, status)
         else:
-            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i], None, False, v, status)
-        if world > 1:
-            vdist.gather_velocities(v, world * B, out=v_all)
+            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i], None, False, vi, status)
+        if async_gather:
+            gather.post(vi, i)
+        elif multi:
+            vdist.gather_velocities(vi, world * B, out=v_all)
 
     def fence():
+        if gather is not None:
+            gather.finish()          # the last update's all-gather belongs to the timed region
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -219,12 +235,12 @@ def main():
             step(args.warmup + i)
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
         status_host = status.cpu().numpy().copy()
-        v_host = v.cpu().numpy().copy()
+        v_host = v_slots[(args.warmup + args.steps - 1) & 1].cpu().numpy().copy() if async_gather else v.cpu().numpy().copy()
 
         # single-update latency with a host synchronisation per update (a control loop's view)
         lat = []
@@ -240,6 +256,8 @@ def main():
         n_prof = min(args.steps, 50)
         for i in range(n_prof):
             step(args.warmup + i)
+        if gather is not None:
+            gather.finish()
         prof = eng.timing_collect()
         eng.timing_enable(False)
         plain = None
@@ -322,7 +340,8 @@ def main():
                              f"through block {cfg.layer}, cosine correspondence, mutual-NN, {params.num_pairs} features "
                              f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update",
                     key=args.config, pairs_per_step_per_gpu=B, tokens=cfg.tokens, dim=cfg.dim,
-                    parallelism=f"dp{world} (frame pairs sharded, v_c all-gather per step)" if world > 1 else "single GPU",
+                    parallelism=(f"dp{world} (frame pairs sharded, v_c all-gather per step"
+                                 f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
                     weights="synthetic seed 0", selection="DENSE" if dense else "ORDER"),
         roofline=roof,
         cpu_baseline=None,
@@ -347,7 +366,7 @@ def main():
                                       "asserted by tests/test_gpu_path.py given identical selections")
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -54,3 +54,44 @@ def gather_velocities(v_local: torch.Tensor, n_pairs: int, group=None, out: torc
     for r, (b2, e2) in enumerate(sizes):
         full[b2:e2] = buf[r * n_max: r * n_max + (e2 - b2)]
     return full
+
+
+class VelocityGather:
+    """The per-update ``v_c`` all-gather issued asynchronously (opt-in: ``bench.py`` with VITVS_ASYNC_GATHER=1).
+
+    Measured on one MI355X in a world of one rank: slower than the synchronous gather (0.577 vs 0.464 ms per update),
+    because work of two hardware queues alternates instead of overlapping on this platform; kept for multi-GPU
+    experiments, where the collective's latency is longer.
+
+    ``post(v_local)`` issues the collective asynchronously: with RCCL it runs on the communicator's own stream behind an
+    event of the caller's stream, so the next update's launches do not wait for it; the previous update's collective is
+    waited for first (it finished long before), and results alternate between two output buffers, so a buffer is never
+    rewritten while a collective may still touch it.  The caller alternates its ``v_local`` buffers the same way
+    (``slot`` = update index & 1).  ``finish()`` waits for the outstanding collective; ``latest`` is the last complete
+    [n_pairs, 6] table.  Equal shards only (the benchmark's layout); ragged shards use ``gather_velocities``.
+    """
+
+    def __init__(self, n_pairs: int, device, dtype=torch.float64, group=None):
+        import torch.distributed as dist
+        self.group = group
+        world = dist.get_world_size(group)
+        if n_pairs % world != 0:
+            raise ValueError("VelocityGather needs equal shards")
+        self.n_pairs = n_pairs
+        self.out = [torch.zeros((n_pairs, 6), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = None
+        self.pending_slot = -1
+        self.latest = self.out[0]
+
+    def post(self, v_local: torch.Tensor, slot: int):
+        import torch.distributed as dist
+        self.finish()
+        self.pending = dist.all_gather_into_tensor(self.out[slot & 1], v_local, group=self.group, async_op=True)
+        self.pending_slot = slot & 1
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.latest = self.out[self.pending_slot]
+            self.pending = None
+        return self.latest
