@@ -533,3 +533,38 @@ def test_dense_correspondence_and_interaction_matrix_at_3136_tokens():
     ref = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
     assert np.array_equal(det["s_uv"][0, :len(mutual), :2], np.asarray(s_star)) and np.array_equal(det["s_uv"][0, :len(mutual), 2:], np.asarray(s))
     assert _rel_l2(v.cpu().numpy()[0], ref["v_c"]) <= 1e-9
+
+
+def test_argmax_parity_over_a_sweep_of_frame_pairs():
+    """Beyond the accepted fixtures: 8 arbitrary frame pairs (ViT-S/16 224², fp32), device arg-maxes against the oracle's
+    similarity matrix — every disagreement must be a <= 2e-5 tie there — and the dense control law given the device's
+    own tables within 1e-9 of the oracle's."""
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
+    depth = synth.depth_pattern()
+    g = cfg.grid
+    exact = 0
+    for seed in range(4100, 4108):
+        des, cur = synth.frame_pair(cfg.img_size, seed)
+        v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+        det = eng.last_details(1)
+        toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+        S = sr.cosine_matrix(toks[0], toks[1], exact_order=False)
+        _, nn1, _, nn2 = sr.nearest_neighbours(S)
+        a1 = _tie_tolerant_agreement(det["nn_1"][0], nn1.numpy(), S.numpy(), 2e-5)
+        a2 = _tie_tolerant_agreement(det["nn_2"][0], nn2.numpy(), S.numpy().T, 2e-5)
+        assert a1 >= 0.98 and a2 >= 0.98
+        exact += int(a1 == 1.0 and a2 == 1.0)
+        n1, n2 = det["nn_1"][0].astype(np.int64), det["nn_2"][0].astype(np.int64)
+        mutual = np.nonzero(n2[n1] == np.arange(cfg.tokens))[0]
+        if int(st[0]) != 0 or len(mutual) in (0, cfg.tokens):
+            continue
+        p1 = torch.from_numpy(np.stack([mutual // g, mutual % g], 1))
+        p2 = torch.from_numpy(np.stack([n1[mutual] // g, n1[mutual] % g], 1))
+        s_star, s = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), len(mutual),
+                                    params.u_max, params.v_max, cfg.img_size)
+        ref = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+        assert _rel_l2(v.cpu().numpy()[0], ref["v_c"]) <= 1e-9
+    print(f"sweep: {exact} of 8 pairs with every arg-max identical to the oracle's")
