@@ -568,3 +568,30 @@ def test_argmax_parity_over_a_sweep_of_frame_pairs():
         ref = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
         assert _rel_l2(v.cpu().numpy()[0], ref["v_c"]) <= 1e-9
     print(f"sweep: {exact} of 8 pairs with every arg-max identical to the oracle's")
+
+
+def test_error_convention_of_the_c_abi():
+    """Nothing throws across the boundary: bad calls return negative codes with a message."""
+    import ctypes as C
+    lib = _lib.load()
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="bf16", max_pairs=1)             # weights NOT loaded
+    frames = torch.zeros((1, cfg.img_size, cfg.img_size, 3), dtype=torch.uint8, device="cuda")
+    out = torch.empty((1, cfg.seq, cfg.dim), dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.vitvs_forward_tokens_dev(eng.handle, 1, C.c_void_p(frames.data_ptr()), C.c_void_p(out.data_ptr()), st)
+    assert rc < 0 and "weights" in _lib.last_error(eng.handle)
+    eng.load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    assert lib.vitvs_forward_tokens_dev(eng.handle, 1, None, C.c_void_p(out.data_ptr()), st) < 0          # null frames
+    assert lib.vitvs_forward_tokens_dev(eng.handle, 5, C.c_void_p(frames.data_ptr()), C.c_void_p(out.data_ptr()), st) < 0  # capacity
+    assert lib.vitvs_extract_facet_dev(eng.handle, 1, C.c_void_p(frames.data_ptr()), 7, C.c_void_p(out.data_ptr()), st) < 0
+    from vitvs_amd.engine import VitvsError
+    with pytest.raises(VitvsError):
+        eng.compute_velocity(np.zeros((64, 64, 3), np.uint8), np.zeros((64, 64, 3), np.uint8), synth.depth_pattern(),
+                             params.intrinsics(), mode=_lib.SELECT_DENSE)     # wrong frame size
+    # a good call still works afterwards
+    des, cur = synth.frame_pair(cfg.img_size, 3)
+    v, s = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER,
+                                selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
+    assert int(s[0]) in (0, 1, 2) and torch.isfinite(v).all()
