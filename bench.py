@@ -8,36 +8,115 @@ intrinsics, weights, one visiting order per update) are resident in HBM before t
 enqueued without host synchronisation (86 stream launches), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--pairs B] [--config KEY]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--pairs B] [--config KEY]
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel class with the largest share of the step,
-timed with HIP event pairs on the launch stream in a second, instrumented pass over the same steps
-(`value` comes from the un-instrumented pass).  `cpu_baseline` is the CPU oracle (PyTorch-CPU fp32
+`--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts the N ranks itself — one process
+per GPU, before this process touches a GPU — and relays rank 0's line; it fails if fewer than N devices are visible.
+Under `torch.distributed.run` (WORLD_SIZE set) each process is one rank, as the driver launches it.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel symbol with the largest share of the step, timed with
+HIP event pairs on the launch stream in a second, instrumented pass over the same steps (`value` comes from the
+un-instrumented pass).  `parity` compares the benchmarked update with the CPU oracle under the same visiting order;
+`secondary` is the fp32 parity mode measured in the same process; `cpu_baseline` is the CPU oracle (PyTorch-CPU fp32
 forward + the reference's correspondence/control-law arithmetic) timed on this host at N = 1.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before HIP initialises (see vit-vs_amd/__init__.py)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import vitvs_amd  # noqa: E402,F401
-from vitvs_amd import _lib, config, synth, weights  # noqa: E402
-from vitvs_amd import dist as vdist  # noqa: E402
-from vitvs_amd.engine import Engine  # noqa: E402
-
 PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
+    ap.add_argument("--config", default="vitb16_224")
+    ap.add_argument("--selection", default="order", choices=["order", "dense"],
+                    help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode leg")
+    ap.add_argument("--no-plain-chain", action="store_true",
+                    help="skip the plain-launch chain of the dominant GEMM (profiler runs: keeps the kernel trace to the steps)")
+    return ap.parse_args(argv)
+
+
+def visible_devices() -> int:
+    """Devices this process could use, WITHOUT initialising HIP (torch.cuda.device_count() does not, on this image)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def rank_environments(n_ranks: int, port: int, base_env=None):
+    """Environment of each child rank (what torch.distributed.run would set)."""
+    envs = []
+    for r in range(n_ranks):
+        e = dict(os.environ if base_env is None else base_env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        envs.append(e)
+    return envs
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv, script=None) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU), wait, relay rank 0's JSON line.
+    This process never touches a GPU (no exec after GPU initialisation, no fork of a GPU-initialised process)."""
+    n = args.gpus
+    share = os.environ.get("VITVS_BENCH_SHARE_GPU") == "1"     # rehearsal: N ranks on fewer GPUs (gloo)
+    have = visible_devices()
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but only {have} HIP device(s) visible; refusing to print a mislabelled line "
+              f"(rehearse the N-rank control flow on fewer GPUs with VITVS_BENCH_SHARE_GPU=1 VITVS_DIST_BACKEND=gloo)",
+              file=sys.stderr)
+        return 2
+    if have < 1:
+        print("bench.py: no HIP device visible", file=sys.stderr)
+        return 2
+    envs = rank_environments(n, free_port())
+    procs = []
+    for r, env in enumerate(envs):
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        sys.stdout.write(out0 or "")
+        return 1
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if not line:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    parsed = json.loads(line[-1])
+    if parsed.get("n_gpus") != n:
+        print(f"bench.py: rank 0 reported n_gpus={parsed.get('n_gpus')} for --gpus {n}", file=sys.stderr)
+        return 1
+    print(line[-1])
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------- work model
 def split_k(m, n, k, bk):
     """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip."""
     tiles = -(-m // 64) * (n // 64)
@@ -80,6 +159,8 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     launches (the instrumented pass, rocprofv3) read ~1.7 us longer per launch than the same kernel costs in the
     un-instrumented stream (tools/launch_floor.hip), so this is the figure that adds up to `ms_per_step`."""
     import ctypes as C
+    import torch
+    from vitvs_amd import _lib
     lib = _lib.load()
     code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32}[prec]
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[prec]
@@ -87,6 +168,7 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     ws = [torch.zeros((n, k), dtype=dt, device=dev) for _ in range(12)]   # 12 weight sets, like the 12 blocks
     part = torch.zeros((slices, m, n), dtype=torch.float32, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
     def chain(r):
         for i in range(r):
             lib.vitvs_op_linear_partial(code, C.c_void_p(a.data_ptr()), C.c_void_p(ws[i % 12].data_ptr()),
@@ -104,55 +186,145 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     return best
 
 
-def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=20.0):
+# ----------------------------------------------------------------------------------------------- CPU oracle legs
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_update(cfg, sd, des, cur, depth, params, order):
+    """One update by the CPU oracle under a given visiting order: tokens -> tables -> the first num_pairs mutual NNs
+    met in `order` -> the reference's law.  Returns dict(nn_1, nn_2, selected, v_c, status)."""
+    import numpy as np
+    import torch
     from oracle import servo_ref as sr
     from oracle import vit_ref
-    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    frames = np.stack([des, cur])
-
-    def update():
-        toks = vit_ref.block_tokens(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
-                                    mean=cfg.mean, std=cfg.std)[:, 1:]
-        return sr.servo_update(toks[0], toks[1], depth, num_pairs=params.num_pairs, input_size=cfg.img_size,
-                               u_max=params.u_max, v_max=params.v_max, fx=params.f_x, fy=params.f_y,
-                               lam=params.lambda_)
-    torch.manual_seed(121)
-    out = update()
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 20 and (time.perf_counter() < t_end or len(times) < 2):
-        t0 = time.perf_counter()
-        out = update()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return out, dict(value=1.0 / med, unit="updates/s", cores=torch.get_num_threads(), kind="port",
-                     sample=f"{len(times)} updates of the same ViT-B/16-class frame pair (median {med * 1e3:.1f} ms, "
-                            f"PyTorch-CPU fp32 forward + reference correspondence loop + numpy pinv)")
+    toks = vit_ref.block_tokens(sd, np.stack([des, cur]), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
+                                layer=cfg.layer, mean=cfg.mean, std=cfg.std)[:, 1:]
+    sim = sr.cosine_matrix(toks[0], toks[1], exact_order=False)
+    _, nn1, _, nn2 = sr.nearest_neighbours(sim)
+    nn1, nn2 = nn1.numpy(), nn2.numpy()
+    t, g, k = cfg.tokens, cfg.grid, params.num_pairs
+    mutual = nn2[nn1] == np.arange(t)
+    out = dict(nn_1=nn1, nn_2=nn2, sim=sim)
+    if mutual.all() or not mutual.any():
+        out.update(status=1, selected=np.zeros(0, np.int64), v_c=np.zeros(6))
+        return out
+    sel = np.array([i for i in np.asarray(order, dtype=np.int64) if mutual[i]][:k], dtype=np.int64)
+    out["selected"] = sel
+    out.update(oracle_law(cfg, params, sel, nn1[sel], depth))
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
-    ap.add_argument("--config", default="vitb16_224", choices=sorted(config.BASELINE_CONFIGS))
-    ap.add_argument("--selection", default="order", choices=["order", "dense"],
-                    help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-plain-chain", action="store_true",
-                    help="skip the plain-launch chain of the dominant GEMM (profiler runs: keeps the kernel trace to the steps)")
-    args = ap.parse_args()
+def oracle_law(cfg, params, sel, matches, depth):
+    import numpy as np
+    import torch
+    from oracle import servo_ref as sr
+    g = cfg.grid
+    p1 = torch.from_numpy(np.stack([sel // g, sel % g], 1).astype(np.int64))
+    p2 = torch.from_numpy(np.stack([matches // g, matches % g], 1).astype(np.int64))
+    s_star, s = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g),
+                                params.num_pairs, params.u_max, params.v_max, cfg.img_size)
+    res = sr.velocity(s_star, s, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+    return dict(v_c=res["v_c"], status=0 if (len(sel) >= 4 or len(sel) == params.num_pairs) else 2)
+
+
+def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=18.0):
+    """The CPU oracle timed on this host: all usable threads (median, p90) and one thread."""
+    import numpy as np
+    import torch
+    order = np.arange(cfg.tokens)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+
+    def timed(n_threads, budget, at_most):
+        torch.set_num_threads(n_threads)
+        oracle_update(cfg, sd, des, cur, depth, params, order)     # warm-up
+        times, t_end = [], time.perf_counter() + budget
+        while len(times) < at_most and (time.perf_counter() < t_end or len(times) < 2):
+            t0 = time.perf_counter()
+            oracle_update(cfg, sd, des, cur, depth, params, order)
+            times.append(time.perf_counter() - t0)
+        return times
+    many = timed(threads, budget_s, 20)
+    one = timed(1, 6.0, 5)
+    torch.set_num_threads(threads)
+    med, p90, med1 = float(np.median(many)), float(np.percentile(many, 90)), float(np.median(one))
+    return dict(value=round(1.0 / med, 3), unit="updates/s", cores=threads, kind="port",
+                p90_ms=round(p90 * 1e3, 2), median_ms=round(med * 1e3, 2), threads_1_value=round(1.0 / med1, 3),
+                threads_1_median_ms=round(med1 * 1e3, 2), cpu_model=cpu_model(), host_cpus=os.cpu_count(),
+                sample=f"{len(many)} updates of the same {cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair on {threads} "
+                       f"threads (median {med * 1e3:.1f} ms, p90 {p90 * 1e3:.1f} ms) and {len(one)} on 1 thread (median "
+                       f"{med1 * 1e3:.1f} ms): PyTorch-CPU fp32 forward + reference correspondence and law (numpy pinv)")
+
+
+def parity_block(eng, cfg, sd, params, des, cur, depth_np, I_cur, I_des, Z, K, order_row, _lib):
+    """Device vs CPU oracle on ONE update under the same visiting order."""
+    import numpy as np
+    v, st = eng.compute_velocity_dev(I_cur[:1], I_des[:1], Z[:1], K[:1], _lib.SELECT_ORDER, order_row[None].contiguous())
+    det = eng.last_details(1)
+    v = v.cpu().numpy()[0]
+    order = order_row.cpu().numpy()
+    ref = oracle_update(cfg, sd, des, cur, depth_np, params, order)
+    k = params.num_pairs
+    dev_sel = det["selected"][0, :k].astype(np.int64)
+    dev_sel = dev_sel[dev_sel >= 0]
+    out = dict(nn_1_agreement=float((det["nn_1"][0] == ref["nn_1"]).mean()),
+               nn_2_agreement=float((det["nn_2"][0] == ref["nn_2"]).mean()),
+               device_status=int(st[0]), oracle_status=int(ref["status"]))
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))   # noqa: E731
+    if ref["status"] == 0 and int(st[0]) == 0:
+        same_sel = bool(np.array_equal(dev_sel, ref["selected"]))
+        out["selected_tokens_agree"] = same_sel
+        out["selected_nn1_agree"] = float((det["nn_1"][0][ref["selected"]] == ref["nn_1"][ref["selected"]]).mean())
+        # end to end: identical when the same tokens were drawn and their matches agree; otherwise another (valid) draw
+        out["v_c_rel_l2"] = rel(v, ref["v_c"])
+        # the law itself: the oracle's law on the DEVICE's draw and matches
+        law = oracle_law(cfg, params, dev_sel, det["nn_1"][0].astype(np.int64)[dev_sel], depth_np)
+        out["v_c_rel_l2_given_device_selection"] = rel(v, law["v_c"])
+        out["note"] = ("v_c is a function of integer pixel features: v_c_rel_l2 is fp64 round-off when the device drew the "
+                       "oracle's tokens with the oracle's matches (selected_tokens_agree and selected_nn1_agree == 1), "
+                       "otherwise it compares two different valid draws")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def timed_updates(eng, step, fence, warmup, steps, dev):
+    import torch
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence()
+    return time.perf_counter() - t0
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
+    import vitvs_amd  # noqa: F401
+    from vitvs_amd import _lib, config, synth, weights
+    from vitvs_amd import dist as vdist
+    from vitvs_amd.engine import Engine
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, launched by torch.distributed.run or "
+                         f"by `python bench.py --gpus N` itself")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the hot path)"
     # VITVS_BENCH_SHARE_GPU=1 + VITVS_DIST_BACKEND=gloo: rehearse the N > 1 control flow on a one-GPU box
     share = os.environ.get("VITVS_BENCH_SHARE_GPU") == "1"
+    if local_rank >= torch.cuda.device_count() and not share:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -163,6 +335,7 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("VITVS_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -177,9 +350,13 @@ def main():
     dense = args.selection == "dense"
     eng = Engine(cfg, params, precision=args.precision, max_pairs=B, max_rows=cfg.tokens if dense else None).load_state_dict(sd)
 
-    # per-rank synthetic inputs, resident in HBM
-    seed0 = synth.ACCEPTED_FRAME_SEEDS[args.config]
-    pairs = [synth.frame_pair(cfg.img_size, seed0 + 1000 * rank + i) for i in range(B)]
+    # per-rank synthetic inputs, resident in HBM.  The headline configuration draws its pairs from the accepted rig
+    # seeds (rank r, pair i -> seed index (r * B + i) mod 8), so the 8-GPU run IS configs[3]'s 8-camera rig.
+    if args.config == "vitb16_224":
+        seeds = [synth.RIG8_FRAME_SEEDS[(rank * B + i) % len(synth.RIG8_FRAME_SEEDS)] for i in range(B)]
+    else:
+        seeds = [synth.ACCEPTED_FRAME_SEEDS[args.config] + 1000 * rank + i for i in range(B)]
+    pairs = [synth.frame_pair(cfg.img_size, s) for s in seeds]
     des_np = np.stack([p[0] for p in pairs])
     cur_np = np.stack([p[1] for p in pairs])
     depth_np = synth.depth_pattern()
@@ -191,7 +368,6 @@ def main():
     gen = torch.Generator().manual_seed(121 + rank)
     orders = torch.stack([torch.stack([torch.randperm(cfg.tokens, generator=gen) for _ in range(B)])
                           for _ in range(total)]).to(torch.int32).to(dev)       # [total, B, T]
-    order_buf = torch.empty((B, cfg.tokens), dtype=torch.int32, device=dev)
     v = torch.zeros((B, 6), dtype=torch.float64, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     v_all = torch.zeros((world * B, 6), dtype=torch.float64, device=dev) if multi else None
@@ -206,17 +382,20 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
 
-    def step(i):
-        # a fresh visiting order per update, already resident (launches are eager, so the pointer may change)
-        vi = v_slots[i & 1] if async_gather else v
-        if dense:
-            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, vi, status)
-        else:
-            eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i], None, False, vi, status)
-        if async_gather:
-            gather.post(vi, i)
-        elif multi:
-            vdist.gather_velocities(vi, world * B, out=v_all)
+    def make_step(engine):
+        def step(i):
+            # a fresh visiting order per update, already resident (launches are eager, so the pointer may change)
+            vi = v_slots[i & 1] if async_gather else v
+            if dense:
+                engine.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, vi, status)
+            else:
+                engine.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, vi, status)
+            if async_gather:
+                gather.post(vi, i)
+            elif multi:
+                vdist.gather_velocities(vi, world * B, out=v_all)
+        return step
+    step = make_step(eng)
 
     def fence():
         if gather is not None:
@@ -227,20 +406,16 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):
-            step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        fence()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
         if multi:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
         status_host = status.cpu().numpy().copy()
         v_host = v_slots[(args.warmup + args.steps - 1) & 1].cpu().numpy().copy() if async_gather else v.cpu().numpy().copy()
+        gathered_ok = None
+        if multi and not async_gather:
+            gathered_ok = bool(torch.equal(v_all[rank * B:(rank + 1) * B], v))    # this rank's rows of the gathered table
 
         # single-update latency with a host synchronisation per update (a control loop's view)
         lat = []
@@ -266,16 +441,33 @@ def main():
             plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
+        parity = None
+        secondary = None
+        if world == 1 and rank == 0 and not args.no_cpu_baseline and not dense:
+            parity = parity_block(eng, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K, orders[0, 0], _lib)
+        if world == 1 and rank == 0 and not args.no_secondary and args.precision != "fp32" and not dense:
+            # the parity mode (fp32 operands on the exact-fp32 MFMA) in the same process, same inputs and orders
+            eng32 = Engine(cfg, params, precision="fp32", max_pairs=B).load_state_dict(sd)
+            s_steps, s_warm = max(10, args.steps // 4), max(3, args.warmup // 4)
+            el32 = timed_updates(eng32, make_step(eng32), fence, s_warm, s_steps, dev)
+            secondary = dict(dtype="fp32", metric="servo_updates_per_sec", value=round(B * s_steps / el32, 2), unit="updates/s",
+                             steps=s_steps, warmup=s_warm, ms_per_step=round(el32 / s_steps * 1e3, 4),
+                             note="parity mode: v_c <= 1e-4 and bit-exact arg-max are asserted in this mode "
+                                  "(tests/test_gpu_path.py); its MFMA ceiling is 157 TFLOP/s -> ~2.2 k updates/s")
+            if not args.no_cpu_baseline:
+                secondary["parity"] = parity_block(eng32, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K,
+                                                   orders[0, 0], _lib)
+            eng32.close()
+
     updates = world * B * args.steps
     value = updates / elapsed
     es = 4 if args.precision == "fp32" else 2
     work = kernel_work(cfg, 2 * B, B, es, binned)
-    overhead_s = 0.0   # the event pairs are stamped by the dispatch itself (hipExtLaunchKernelGGL): no correction
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
             continue
-        avg = max(ms / cnt * 1e-3 - overhead_s, 1e-7)
+        avg = max(ms / cnt * 1e-3, 1e-7)
         fl, by = work[name]
         kernels[name] = dict(launches_per_step=cnt / n_prof, avg_us=round(avg * 1e6, 3),
                              step_share_us=round(avg * cnt / n_prof * 1e6, 2),
@@ -287,13 +479,16 @@ def main():
     for k in kernels:
         if k not in ("proj", "fc2"):
             groups[k] = [k]
-    def g_share(g): return sum(kernels[c]["step_share_us"] for c in groups[g] if c in kernels)
+
+    def g_share(g):
+        return sum(kernels[c]["step_share_us"] for c in groups[g] if c in kernels)
     dom = max(groups, key=g_share)
     members = [c for c in groups[dom] if c in kernels]
     launches = sum(kernels[c]["launches_per_step"] for c in members)
     avg_s = g_share(dom) / launches * 1e-6
     fl = sum(work[c][0] * kernels[c]["launches_per_step"] for c in members) / launches
     by = sum(work[c][1] * kernels[c]["launches_per_step"] for c in members) / launches
+
     def narrow_tile(m, n, kk):   # mirror of the tile choice for the N = D layers in csrc/gemm.hip
         s_ = split_k(m, n, kk, 128 // es)
         if s_ == 1 and n % 128 == 0 and -(-m // 128) * (n // 128) >= 256:
@@ -302,25 +497,29 @@ def main():
         return "64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1"
     symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},{narrow_tile(2 * B * cfg.seq, cfg.dim, cfg.hidden)}>:EpiPartial",
               "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
-              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore", "attention": "attention_f32_kernel" if prec_tag == "f32" else f"attention_16_kernel<{prec_tag}>"}.get(dom, dom)
-    traffic, mfma_busy = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore",
+              "attention": "attention_f32_kernel" if prec_tag == "f32" else f"attention_16_kernel<{prec_tag}>"}.get(dom, dom)
+    # HBM traffic (PMC) comes from separate rocprofv3 --pmc passes of this same command, never from this run: the line
+    # says which committed file and which commit of the kernels it was measured on, and mixes it into no live ratio.
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(ROOT, TRAFFIC_PROFILE)
     if os.path.isfile(pmc_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1:
         with open(pmc_path) as fh:
-            pmc = json.load(fh).get(symbol, {})
-        traffic = pmc.get("hbm_bytes_per_launch")
-        mfma_busy = pmc.get("mfma_busy_cycles_per_launch")
+            blob = json.load(fh)
+        entry = blob.get("kernels", blob).get(symbol)
+        if entry:
+            traffic = entry.get("hbm_bytes_per_launch")
+            traffic_source = dict(file=TRAFFIC_PROFILE, symbol=symbol, measured_at_commit=blob.get("git_commit"),
+                                  command=blob.get("command"), mfma_busy_cycles_per_launch=entry.get("mfma_busy_cycles_per_launch"),
+                                  note="separate --pmc FETCH_SIZE / WRITE_SIZE (and SQ_VALU_MFMA_BUSY_CYCLES) passes; "
+                                       "FETCH_SIZE doubled per the gfx950 correction")
     mfma_bound = dom in ("qkv", "fc1", "attention", "patch_embed", "gram_argmax", "linear_partial(proj+fc2)")
     if mfma_bound:
         peak = PEAK_MFMA["fp32" if dom == "gram_argmax" else args.precision]
         roof = dict(kernel=symbol, classes=members, bound="mfma", achieved=round(fl / avg_s / 1e12, 3), peak=peak / 1e12,
-                    unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic,
+                    unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
-                    avg_launch_us=round(avg_s * 1e6, 3), event_pair_overhead_us=round(overhead_s * 1e6, 3))
-        if mfma_busy:
-            # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (separate pass, profiles/): busy cycles over the 1024 SIMDs of the chip
-            roof.update(mfma_busy_cycles_per_launch=mfma_busy,
-                        mfma_util_pmc=round(mfma_busy / (1024 * avg_s * 2.4e9), 5))
+                    avg_launch_us=round(avg_s * 1e6, 3))
         if plain and dom == "linear_partial(proj+fc2)":
             # the same kernel in a chain of plain launches (what the un-instrumented step pays per launch)
             p_us = sum(plain[c] * kernels[c]["launches_per_step"] for c in members) / launches
@@ -328,9 +527,8 @@ def main():
                         frac_plain=round(fl / (p_us * 1e-6) / peak, 5))
     else:
         roof = dict(kernel=symbol, classes=members, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9,
-                    unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic,
-                    algorithmic_bytes_per_launch=by, avg_launch_us=round(avg_s * 1e6, 3),
-                    event_pair_overhead_us=round(overhead_s * 1e6, 3))
+                    unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic, traffic_source=traffic_source,
+                    algorithmic_bytes_per_launch=by, avg_launch_us=round(avg_s * 1e6, 3))
 
     out = dict(
         metric="servo_updates_per_sec", value=round(value, 2), unit="updates/s", n_gpus=world, steps=args.steps,
@@ -342,9 +540,11 @@ def main():
                     key=args.config, pairs_per_step_per_gpu=B, tokens=cfg.tokens, dim=cfg.dim,
                     parallelism=(f"dp{world} (frame pairs sharded, v_c all-gather per step"
                                  f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
-                    weights="synthetic seed 0", selection="DENSE" if dense else "ORDER"),
+                    weights="synthetic seed 0", frame_seeds=seeds, selection="DENSE" if dense else "ORDER"),
         roofline=roof,
         cpu_baseline=None,
+        parity=parity,
+        secondary=secondary,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),
                   tflops=round(cfg.flops_per_pair(binned) * value / world / 1e12, 3),
                   frac_of_mfma_peak=round(cfg.flops_per_pair(binned) * value / world / PEAK_MFMA[args.precision], 5),
@@ -355,19 +555,24 @@ def main():
         status=[int(s) for s in status_host],
         v_c=[float(x) for x in v_host[0]],
     )
+    if gathered_ok is not None:
+        out["gathered_rows_match_local"] = gathered_ok
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        ref, base = cpu_baseline(cfg, sd, des_np[0], cur_np[0], depth_np, params)
-        out["cpu_baseline"] = base
-        det = eng.last_details(1)
-        if ref.get("corr") is not None:
-            out["parity"] = dict(nn_1_agreement=float((det["nn_1"][0] == ref["corr"]["nn_1"].numpy()).mean()),
-                                 nn_2_agreement=float((det["nn_2"][0] == ref["corr"]["nn_2"].numpy()).mean()),
-                                 note="GPU (this dtype) vs CPU oracle argmax on the benchmarked pair; v_c parity is "
-                                      "asserted by tests/test_gpu_path.py given identical selections")
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, des_np[0], cur_np[0], depth_np, params)
     if rank == 0:
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

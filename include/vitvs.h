@@ -15,7 +15,9 @@
  *     the end of the call's work.  The un-suffixed forms take HOST pointers, copy, run and wait.
  *   - inputs are borrowed for the duration of the call; outputs go to caller-allocated buffers;
  *     the handle owns the device weights and workspaces.  One in-flight call per handle; a handle
- *     is bound to the HIP device that was current when it was created.
+ *     is bound to the HIP device that was current when it was created: every entry point that takes
+ *     a handle runs on that device (and restores the caller's current device before returning), so
+ *     handles of several GPUs may be driven from one thread.
  *   - images are RGB uint8, HWC, already resized to img_size x img_size (reference:
  *     vitvs_v2.py:474-475 PIL resize happens before the path; dinov2_extractor.py:177-191);
  *     vitvs_resize_frames_dev does that resize on the device, bit-identically to PIL.
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VITVS_ABI_VERSION 1
+#define VITVS_ABI_VERSION 2   /* 2: num_pairs became a per-call argument of the velocity / servo entry points */
 #define VITVS_API __attribute__((visibility("default")))
 
 typedef struct vitvs_handle vitvs_handle;
@@ -72,7 +74,7 @@ typedef struct vitvs_config {
     int32_t precision;    /* vitvs_precision of the ViT GEMMs/attention; the correspondence and the law are fp32/fp64 */
     int32_t binned;       /* 1: 3x3 log-bin descriptors (use_feature_binning, dinov2_extractor.py:265-311) */
     /* control law (reference: config.yaml:1-17; vitvs_v2.py:278-295) */
-    int32_t num_pairs;
+    int32_t num_pairs;    /* default feature-pair count of a call that passes num_pairs <= 0 */
     int32_t u_max, v_max; /* camera resolution; also the depth image size */
     double lambda;
     /* capacity */
@@ -105,16 +107,20 @@ VITVS_API int vitvs_weights_ready(const vitvs_handle* h);
  *   K                double [n_pairs][4] = fx, fy, cx, cy
  *   select_mode      vitvs_select; `selection` int32: EXPLICIT [n_pairs][num_pairs] token ids with
  *                    n_selected[n_pairs] counts; ORDER [n_pairs][T]; DENSE ignored (NULL)
+ *   num_pairs        feature pairs of the control law for THIS call (the reference's Controller.num_pairs, which its
+ *                    callers change between calls: 24 in the servo loop, 48 in find_and_set_best_pose,
+ *                    vitvs_v2.py:1151-1189); 1 .. cfg.max_rows, or <= 0 for cfg.num_pairs
  *   v_c              double [n_pairs][6] = vx, vy, vz, wx, wy, wz (camera optical frame)
  *   status           int32 [n_pairs] vitvs_status
  * The return value is < 0 on error, else 0 (per-pair statuses are in `status`). */
 VITVS_API int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                                int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
-                               const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
-                               void* stream);
+                               const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
+                               int32_t* status, void* stream);
 VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
-                           const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status);
+                           const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
+                           int32_t* status);
 
 /* --- in front of it: camera frame -> extractor input -----------------------------------------------
  * goal_image.resize((S, S)) / latest_pil_image.resize((S, S)) (vitvs_v2.py:474-475; PIL default filter BICUBIC,
@@ -148,7 +154,7 @@ VITVS_API int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const
  * :566-586, :613-659): nn_1, nn_2 int32 [T], sim_1 fp32 [T] for ONE pair. */
 VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, const int32_t* nn_2, const float* sim_1,
                             const uint16_t* Z_mm, const double* K, int32_t select_mode, const int32_t* selection,
-                            int32_t n_selected, double* v_c, int32_t* status, void* stream);
+                            int32_t n_selected, int32_t num_pairs, double* v_c, int32_t* status, void* stream);
 
 /* --- introspection of the last compute_velocity / servo call (device -> host copies, synchronising).
  * What detect_features() returns besides v_c (vitvs_v2.py:523) and what the parity tests check.
@@ -156,6 +162,7 @@ VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t*
  *   info int32 [n_pairs][8]: n_mutual, n_feature_rows, same_image, n_matched, svd_sweeps, L_rows, 0, 0
  *   selected int32 [n_pairs][max_rows] token ids of the desired frame (-1 = zero-padded row)
  *   s_uv int32 [n_pairs][max_rows][4] = u*, v*, u, v ; feat double [n_pairs][max_rows][4] = Z, x, y, sim
+ *        (feat[..][3] over the first n_matched rows is the reference's sim_selected_12, vitvs_v2.py:523, 1167-1174)
  *   L double [n_pairs][7][2*max_rows] column-major: 6 columns of L_e then e.
  * Any pointer may be NULL. */
 VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,

@@ -231,6 +231,68 @@ def make_e2e(key: str, frame_seed: int, binned: bool, weight_seed: int = 0, stor
     np.savez_compressed(os.path.join(GOLDEN, f"e2e_{key}.npz"), **blob)
 
 
+# ------------------------------------------------------------------ D: 8-camera rig (BASELINE.json configs[3])
+def make_rig8(key: str = "vitb16_224", n_pairs: int = 8, first_seed: int = 20250715):
+    """8 independent frame pairs that meet the acceptance rule (4 <= mutual < T, mean(sim_1) <= 0.99, margins >= 1e-4),
+    pair 0 being the headline fixture's pair; per pair the reference's tables, draw and v_c."""
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    depth = synth.depth_pattern()
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    blob, seeds, seed = {}, [], first_seed
+    while len(seeds) < n_pairs:
+        des, cur = synth.frame_pair(cfg.img_size, seed)
+        toks = vit_ref.block_tokens(sd, np.stack([des, cur]), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
+                                    layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+        res = reference_post_vit(toks[0, 1:], toks[1, 1:], depth, params, input_size=cfg.img_size)
+        t = cfg.tokens
+        mutual = int((res["nn_2"].astype(np.int64)[res["nn_1"].astype(np.int64)] == np.arange(t)).sum())
+        ok = (int(res["status"]) == 0 and 4 <= mutual < t and float(res["mean_sim_1"]) <= 0.99 and
+              min(float(res["margin_rows"]), float(res["margin_cols"])) >= 1e-4)
+        print(f"rig8 seed {seed}: mutual={mutual} margins={float(res['margin_rows']):.2e}/{float(res['margin_cols']):.2e} "
+              f"{'accepted' if ok else 'rejected'}")
+        if ok:
+            i = len(seeds)
+            seeds.append(seed)
+            for k2 in ("nn_1", "nn_2", "sim_1", "points1", "s_uv", "s_uv_star", "v_c", "margin_rows", "margin_cols"):
+                blob[f"pair{i}/{k2}"] = res[k2]
+        seed += 1
+    blob["frame_seeds"] = np.array(seeds, dtype=np.int64)
+    blob["weight_seed"] = np.int64(0)
+    np.savez_compressed(os.path.join(GOLDEN, f"rig8_{key}.npz"), **blob)
+
+
+# ------------------------------------------------------------------ E: rotation compensation (vitvs_v2.py:1151-1189)
+def make_rotation(key: str = "vits16_224"):
+    """The four views of find_and_set_best_pose against one goal: per view the reference's draw with num_pairs = 48
+    (consecutive draws from one RNG stream seeded with 121, as in the reference's loop) and its score
+    sim_selected_12.mean().  The views are the current frame turned by 90 degree steps, un-rotated at index 1."""
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS[key])
+    views = [np.rot90(cur, k).copy() for k in (1, 0, 2, 3)]
+    toks = vit_ref.block_tokens(sd, np.stack([des] + views), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
+                                layer=cfg.layer, mean=cfg.mean, std=cfg.std)[:, 1:]
+    _, _, fcb = rx.load_correspondence_functions()
+    torch.manual_seed(SELECT_SEED)
+    blob = dict(frame_seed=np.int64(synth.ACCEPTED_FRAME_SEEDS[key]), weight_seed=np.int64(0), num_pairs=np.int32(48),
+                rot90_k=np.array([1, 0, 2, 3], dtype=np.int32))
+    best, best_mean = -1, float("-inf")
+    for i in range(4):
+        p1, p2, sim = fcb(toks[0][None, None], toks[1 + i][None, None], num_pairs=48)
+        assert p1 is not None
+        mean = sim.mean().item()                               # vitvs_v2.py:1174
+        if mean > best_mean:                                   # :1177
+            best_mean, best = mean, i
+        blob[f"view{i}/points1"] = p1.numpy()
+        blob[f"view{i}/points2"] = p2.numpy()
+        blob[f"view{i}/sim_selected"] = sim.reshape(-1).numpy()
+        blob[f"view{i}/score"] = np.float64(mean)
+        print(f"rotation view {i}: {p1.shape[0]} pairs, score {mean:.6f}")
+    blob["best"] = np.int32(best)
+    np.savez_compressed(os.path.join(GOLDEN, f"rotation_{key}.npz"), **blob)
+
+
 def main():
     if not rx.available():
         raise SystemExit("the reference tree is not mounted; goldens can only be generated in the build container")
@@ -241,6 +303,10 @@ def main():
         make_corr_cases()
     if "pieces" in which:
         make_extractor_pieces()
+    if "rig8" in which:
+        make_rig8()
+    if "rotation" in which:
+        make_rotation()
     for key, binned in (("vits16_224", True), ("vitb16_224", True), ("vits14_308", True),
                         ("vitb8_448", False), ("vitl14_518", False)):
         if key in which:

@@ -285,33 +285,82 @@ def test_compute_velocity_fp32_many_tokens(key):
     a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, 2e-5)
     assert a1 >= 0.99 and a2 >= 0.99
     assert st == 0
-    # v_c depends on nn_1 at the selected tokens only; require those to agree, then the law must match
+    # v_c depends on nn_1 at the selected tokens only.  Where the device's arg-max at a selected token is the other
+    # side of a <= 2e-5 tie (asserted above for every token), the oracle's law is evaluated on the device's own match
+    # for that token; either way v_c is checked — never skipped.
     sel = _ids(case["points1"], cfg.grid)
-    if np.array_equal(det["nn_1"][0][sel], case["nn_1"][sel]):
-        assert _rel_l2(v, case["v_c"]) <= 1e-9
+    g = cfg.grid
+    same = np.array_equal(det["nn_1"][0][sel], case["nn_1"][sel])
+    if same:
+        want = case["v_c"]
+    else:
+        params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+        n1 = det["nn_1"][0].astype(np.int64)[sel]
+        p1 = torch.from_numpy(np.stack([sel // g, sel % g], 1).astype(np.int64))
+        p2 = torch.from_numpy(np.stack([n1 // g, n1 % g], 1))
+        s_star, s = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g),
+                                    params.num_pairs, params.u_max, params.v_max, cfg.img_size)
+        want = sr.velocity(s_star, s, synth.depth_pattern(), params.f_x, params.f_y, params.c_x, params.c_y,
+                           params.lambda_)["v_c"]
+    print(f"{key}: selected tokens' nn_1 {'identical to' if same else 'tie-different from'} the fixture's; "
+          f"agreement nn_1 {a1:.4f} nn_2 {a2:.4f}")
+    assert _rel_l2(v, want) <= 1e-9 <= VC_TOL
 
 
-def test_compute_velocity_bf16_reports_agreement():
-    """bf16 throughput mode: not bit-exact by construction; it must stay close to the fp32 oracle."""
-    case, det, v, st = _e2e("vitb16_224", "plain", "bf16")
-    agree1 = float((det["nn_1"][0] == case["nn_1"]).mean())
-    agree2 = float((det["nn_2"][0] == case["nn_2"]).mean())
-    print(f"bf16 argmax agreement nn_1={agree1:.3f} nn_2={agree2:.3f} v_c rel err={_rel_l2(v, case['v_c']):.3e}")
-    assert st == 0 and np.all(np.isfinite(v))
-    assert agree1 >= 0.85 and agree2 >= 0.85
-    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-2)
+# 16-bit operand modes (the headline dtype): arg-max agreement with the fp32 oracle and v_c, over the 8 accepted
+# ViT-B/16 pairs of the rig fixture.  v_c is a function of INTEGER pixel features, so in these modes it is either the
+# oracle's to fp64 round-off (same selected tokens, same matches) or a different, equally valid feature draw; the test
+# asserts the former whenever the selected tokens and their matches agree, and reports how often they do.
+MODE_BARS = {"bf16": dict(agree=0.90, sim_atol=2e-2), "fp16": dict(agree=0.97, sim_atol=3e-3)}
 
 
-def test_compute_velocity_fp16_stays_close_to_the_fp32_oracle():
-    """fp16 operand mode (BASELINE.json configs[4] names fp16): 11-bit significand, so it must sit much closer to the fp32
-    oracle than bf16 does — arg-max agreement and similarities."""
-    case, det, v, st = _e2e("vitb16_224", "plain", "fp16")
-    agree1 = float((det["nn_1"][0] == case["nn_1"]).mean())
-    agree2 = float((det["nn_2"][0] == case["nn_2"]).mean())
-    print(f"fp16 argmax agreement nn_1={agree1:.3f} nn_2={agree2:.3f} v_c rel err={_rel_l2(v, case['v_c']):.3e}")
-    assert st == 0 and np.all(np.isfinite(v))
-    assert agree1 >= 0.97 and agree2 >= 0.97
-    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=3e-3)
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_16bit_modes_over_8_accepted_pairs(precision):
+    blob = load_golden("rig8_vitb16_224.npz")
+    cfg = config.baseline_config("vitb16_224")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    depth = synth.depth_pattern()
+    g, t, k = cfg.grid, cfg.tokens, params.num_pairs
+    bars = MODE_BARS[precision]
+    agree1, agree2, same_sel, checked = [], [], 0, 0
+    for i, seed in enumerate(int(x) for x in blob["frame_seeds"]):
+        case = golden_case(blob, f"pair{i}")
+        des, cur = synth.frame_pair(cfg.img_size, seed)
+        # (1) given the reference's selection: v_c matches whenever nn_1 agrees at the selected tokens
+        sel = _ids(case["points1"], g)
+        v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+        det = eng.last_details(1)
+        assert int(st[0]) == 0 and np.all(np.isfinite(v.cpu().numpy()))
+        agree1.append(float((det["nn_1"][0] == case["nn_1"]).mean()))
+        agree2.append(float((det["nn_2"][0] == case["nn_2"]).mean()))
+        np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=bars["sim_atol"])
+        if np.array_equal(det["nn_1"][0][sel], case["nn_1"][sel]):
+            checked += 1
+            assert _rel_l2(v.cpu().numpy()[0], case["v_c"]) <= 1e-9 <= VC_TOL
+        # (2) given the same visiting order: the device picks the same tokens iff its mutual-NN set agrees on the
+        # visited prefix; then v_c equals the oracle law on those tokens
+        order = np.random.default_rng(1000 + i).permutation(t).astype(np.int32)
+        n1r, n2r = case["nn_1"].astype(np.int64), case["nn_2"].astype(np.int64)
+        mutual = set(np.nonzero(n2r[n1r] == np.arange(t))[0].tolist())
+        want_sel = np.array([x for x in order if x in mutual][:k], dtype=np.int64)
+        v2, st2 = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order[None])
+        det2 = eng.last_details(1)
+        got_sel = det2["selected"][0, :k].astype(np.int64)
+        if np.array_equal(got_sel, want_sel) and np.array_equal(det2["nn_1"][0][want_sel], n1r[want_sel]):
+            same_sel += 1
+            p1 = torch.from_numpy(np.stack([want_sel // g, want_sel % g], 1))
+            p2 = torch.from_numpy(np.stack([n1r[want_sel] // g, n1r[want_sel] % g], 1))
+            s_star, s_ = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), k,
+                                         params.u_max, params.v_max, cfg.img_size)
+            ref = sr.velocity(s_star, s_, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+            assert _rel_l2(v2.cpu().numpy()[0], ref["v_c"]) <= 1e-9 <= VC_TOL
+    print(f"{precision}: argmax agreement with the fp32 oracle over 8 pairs: nn_1 mean {np.mean(agree1):.4f} min {min(agree1):.4f}, "
+          f"nn_2 mean {np.mean(agree2):.4f} min {min(agree2):.4f}; v_c checked (<= 1e-9) on {checked}/8 pairs given the "
+          f"reference selection, on {same_sel}/8 given the same visiting order (the rest drew different, valid features)")
+    assert np.mean(agree1) >= bars["agree"] and np.mean(agree2) >= bars["agree"]
+    assert checked >= 1
 
 
 @pytest.mark.parametrize("key", ["vitl14_518"])
@@ -351,6 +400,152 @@ def test_batched_pairs_and_shared_goal():
     assert torch.equal(vs, vr) and torch.equal(ss, sr_)
 
 
+def test_rig_of_8_vitb16_pairs_in_one_call():
+    """BASELINE.json configs[3] on one GPU: 8 ViT-B/16 224² pairs in ONE call (what one rank of the rig runs when the
+    rig is smaller than the camera count).  Against the reference-generated fixture: arg-max tables bit-exact and v_c
+    <= 1e-9 for every pair given the reference's draw (pair 0 is the headline fixture's pair); against 8 single calls:
+    identical tables and bit-identical v_c (the law is fp64 on integer features; the many-row GEMM tiles sum K in another
+    order than the one-pair tiles, so similarities may differ in the last bits)."""
+    blob = load_golden("rig8_vitb16_224.npz")
+    cfg = config.baseline_config("vitb16_224")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    seeds = [int(x) for x in blob["frame_seeds"]]
+    pairs = [synth.frame_pair(cfg.img_size, s_) for s_ in seeds]
+    des = np.stack([p[0] for p in pairs])
+    cur = np.stack([p[1] for p in pairs])
+    depth = np.stack([synth.depth_pattern()] * 8)
+    sels = [_ids(blob[f"pair{i}/points1"], cfg.grid) for i in range(8)]
+    eng = _engine(cfg, params, precision="fp32", max_pairs=8).load_state_dict(sd)
+    vb, sb = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=sels)
+    detb = eng.last_details(8)
+    vb = vb.cpu().numpy()
+    head = golden_case(load_golden("e2e_vitb16_224.npz"), "plain")
+    assert _rel_l2(vb[0], head["v_c"]) <= 1e-9 and np.array_equal(detb["nn_1"][0], head["nn_1"])
+    for i in range(8):
+        case = golden_case(blob, f"pair{i}")
+        assert int(sb[i]) == 0
+        assert np.array_equal(detb["nn_1"][i], case["nn_1"]) and np.array_equal(detb["nn_2"][i], case["nn_2"])
+        assert np.array_equal(detb["s_uv"][i, :params.num_pairs, 2:4], case["s_uv"])
+        assert _rel_l2(vb[i], case["v_c"]) <= 1e-9 <= VC_TOL
+        v1, s1 = eng.compute_velocity(cur[i], des[i], depth[i], params.intrinsics(), mode=_lib.SELECT_EXPLICIT,
+                                      selection=[sels[i]])
+        det1 = eng.last_details(1)
+        assert np.array_equal(det1["nn_1"][0], detb["nn_1"][i]) and np.array_equal(det1["nn_2"][0], detb["nn_2"][i])
+        assert np.array_equal(v1.cpu().numpy()[0], vb[i])
+        np.testing.assert_allclose(det1["sim_1"][0], detb["sim_1"][i], rtol=0, atol=2e-6)
+
+
+def test_num_pairs_is_a_per_call_argument():
+    """The reference changes Controller.num_pairs between calls (24 in the loop, 48 in the rotation search); one handle
+    serves both, and the 48-pair call equals a handle created with num_pairs = 48."""
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vits16_224"])
+    depth = synth.depth_pattern()
+    order = torch.randperm(cfg.tokens, generator=torch.Generator().manual_seed(8)).to(torch.int32)[None]
+    p24 = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, p24, precision="fp32", max_pairs=1).load_state_dict(sd)          # max_rows defaults to 48
+    v24, _ = eng.compute_velocity(cur, des, depth, p24.intrinsics(), mode=_lib.SELECT_ORDER, selection=order)
+    d24 = eng.last_details(1)
+    v48, _ = eng.compute_velocity(cur, des, depth, p24.intrinsics(), mode=_lib.SELECT_ORDER, selection=order, num_pairs=48)
+    d48 = eng.last_details(1)
+    assert int(d24["info"][0, 1]) == 24 and int(d48["info"][0, 1]) == 48
+    assert d48["selected"][0, :24].tolist() == d24["selected"][0, :24].tolist()
+    eng48 = _engine(cfg, p24.replace(num_pairs=48), precision="fp32", max_pairs=1).load_state_dict(sd)
+    w48, _ = eng48.compute_velocity(cur, des, depth, p24.intrinsics(), mode=_lib.SELECT_ORDER, selection=order)
+    assert torch.equal(v48, w48) and not torch.equal(v24, v48)
+    from vitvs_amd.engine import VitvsError
+    with pytest.raises(VitvsError):
+        eng.compute_velocity(cur, des, depth, p24.intrinsics(), mode=_lib.SELECT_ORDER, selection=order, num_pairs=49)
+
+
+def test_rotation_compensation_scores_match_the_reference():
+    """find_and_set_best_pose (vitvs_v2.py:1151-1189): 4 views against one goal, num_pairs = 48, score = mean selected
+    similarity.  Given the reference's draws (fixture generated by the reference's find_correspondences_batch), the four
+    device scores equal the reference's; Controller.best_rotation (own draws, one batch, shared goal forward) picks the
+    same view."""
+    from vitvs_amd import servo
+    blob = load_golden("rotation_vits16_224.npz")
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    views = np.stack([np.rot90(cur, int(k)).copy() for k in blob["rot90_k"]])
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=4).load_state_dict(sd)
+    k = int(blob["num_pairs"])
+    sels = [_ids(blob[f"view{i}/points1"], cfg.grid) for i in range(4)]
+    depth = np.zeros((4, params.v_max, params.u_max), np.uint16)
+    eng.compute_velocity(views, des[None], depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=sels,
+                         des_shared=True, num_pairs=k)
+    det = eng.last_details(4)
+    scores = []
+    for i in range(4):
+        assert int(det["info"][i, 3]) == k
+        sim = det["feat"][i, :k, 3].astype(np.float32)
+        np.testing.assert_allclose(sim, blob[f"view{i}/sim_selected"], rtol=0, atol=2e-6)
+        got_p2 = det["nn_1"][i][sels[i]]
+        assert np.array_equal(got_p2, _ids(blob[f"view{i}/points2"], cfg.grid))
+        scores.append(float(sim.mean()))
+        assert abs(scores[-1] - float(blob[f"view{i}/score"])) <= 2e-6
+    assert int(np.argmax(scores)) == int(blob["best"])
+    ctl = servo.Controller(eng, goal_image=des, selection="order")
+    best, own = ctl.best_rotation(list(views), generator=torch.Generator().manual_seed(1))
+    assert best == int(blob["best"]) and all(s_ is not None for s_ in own)
+    assert ctl.num_pairs == params.num_pairs                       # restored (never changed): 48 applied to those calls only
+    for i in range(4):                                              # another draw of 48 of the same mutual NNs: close, not equal
+        assert abs(own[i] - float(blob[f"view{i}/score"])) <= 0.03
+
+
+def test_graph_replay_matches_eager(monkeypatch):
+    """VITVS_GRAPH=1 (read at vitvs_create): the update replayed as one captured hipGraph gives bit-identical results,
+    also when the visiting order changes from update to update (it is not part of the graph's key)."""
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vits16_224"])
+    dev = torch.device("cuda")
+    I_cur, I_des = torch.from_numpy(cur[None]).to(dev), torch.from_numpy(des[None]).to(dev)
+    Z = torch.from_numpy(synth.depth_pattern()[None]).to(dev)
+    K = torch.tensor([params.intrinsics()], dtype=torch.float64, device=dev)
+    gen = torch.Generator().manual_seed(11)
+    orders = [torch.randperm(cfg.tokens, generator=gen).to(torch.int32)[None].to(dev) for _ in range(4)]
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VITVS_GRAPH", mode)
+        eng = _engine(cfg, params, precision="bf16", max_pairs=1).load_state_dict(sd)
+        out = []
+        with torch.cuda.stream(torch.cuda.Stream()):              # graphs need a non-null stream
+            for o in orders + orders[:2]:
+                v, st = eng.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, o)
+                torch.cuda.synchronize()
+                out.append((v.cpu().numpy().copy(), int(st[0]), eng.last_details(1)["selected"].copy()))
+        results[mode] = out
+        eng.close()
+    for a, b in zip(results["0"], results["1"]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    assert not np.array_equal(results["1"][0][0], results["1"][1][0])     # different orders do give different draws
+
+
+def test_two_handles_interleaved():
+    """Two handles (different models, precisions and capacities) driven alternately from one thread: each keeps its own
+    weights / workspaces, and the per-device opt-in for > 64 KiB of LDS is in place for both."""
+    ca, cb = config.baseline_config("vits16_224"), _tiny_cfg(True)
+    pa = config.ServoParams(dino_input_size=ca.img_size, use_feature_binning=False)
+    pb = config.ServoParams(dino_input_size=cb.img_size, use_feature_binning=False)
+    ea = _engine(ca, pa, precision="bf16", max_pairs=2).load_state_dict(weights.synthetic_state_dict(ca, 0))
+    eb = _engine(cb, pb, precision="fp32", max_pairs=1, max_rows=cb.tokens).load_state_dict(weights.synthetic_state_dict(cb, 4))
+    fa = np.stack(synth.frame_pair(ca.img_size, 31))
+    fb = np.stack(synth.frame_pair(cb.img_size, 32))
+    ta0, tb0 = ea.forward_tokens(fa).cpu(), eb.forward_tokens(fb).cpu()
+    for _ in range(3):
+        tb = eb.forward_tokens(fb).cpu()
+        ta = ea.forward_tokens(fa).cpu()
+        assert torch.equal(ta, ta0) and torch.equal(tb, tb0)
+    ref = _oracle_tokens(cb, weights.synthetic_state_dict(cb, 4), fb)
+    assert float((tb0 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_host_pointer_entry_point_matches_device_entry_point():
     import ctypes as C
     cfg = config.baseline_config("vits16_224")
@@ -365,7 +560,7 @@ def test_host_pointer_entry_point_matches_device_entry_point():
     st = np.zeros(1, np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     rc = eng.lib.vitvs_compute_velocity(eng.handle, 1, p(np.ascontiguousarray(cur)), p(np.ascontiguousarray(des)), 0,
-                                        p(depth), p(K), _lib.SELECT_DENSE, None, None, p(v), p(st))
+                                        p(depth), p(K), _lib.SELECT_DENSE, None, None, 0, p(v), p(st))
     assert rc == 0 and int(st[0]) == int(sd_[0])
     assert np.array_equal(v, vd.cpu().numpy()[0])
 
@@ -405,6 +600,35 @@ def test_controller_adapter_reproduces_reference_update():
     cands = [np.rot90(cur, k).copy() for k in (1, 0, 2, 3)]
     best, scores = ctl.best_rotation(cands)
     assert best == 1 and len(scores) == 4
+
+
+def test_controller_with_camera_resolution_frames_and_reference_selection():
+    """640x480 camera frames (the normal case): the adapter resizes on the device (a CUDA tensor reaches the reference-
+    selection path) and the update equals the one computed from host-side PIL-identical resizes."""
+    from vitvs_amd import servo
+    from oracle import resize_ref
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd)
+    rng = np.random.default_rng(77)
+    goal = synth.texture(640, 5)[:480]                                  # 480 x 640 x 3
+    cam = synth.warp_similarity(goal, shift=(14.0, -8.0), rot_deg=3.0, scale=1.02, seed=6)
+    depth = synth.depth_pattern()
+    ctl = servo.Controller(eng, goal_image=goal, selection="reference")
+    ctl.image_callback_rgb(cam)
+    ctl.image_callback_depth(depth)
+    torch.manual_seed(121)
+    ctl.ibvs()
+    assert ctl.v_c is not None and np.all(np.isfinite(ctl.v_c)) and ctl.last_status in (0, 2)
+    small_goal, small_cam = resize_ref.resize_bicubic_u8(goal, cfg.img_size), resize_ref.resize_bicubic_u8(cam, cfg.img_size)
+    ctl2 = servo.Controller(eng, goal_image=small_goal, selection="reference")
+    ctl2.image_callback_rgb(small_cam)
+    ctl2.image_callback_depth(depth)
+    torch.manual_seed(121)
+    ctl2.ibvs()
+    assert np.array_equal(ctl.v_c, ctl2.v_c)
+    del rng
 
 
 def test_controller_failure_counter_raises_like_the_reference():

@@ -134,3 +134,48 @@ def test_end_to_end_fixture(key, binned):
         assert np.array_equal(out["corr"]["nn_2"].numpy(), case["nn_2"])
         assert np.array_equal(out["s_uv"], case["s_uv"]) and np.array_equal(out["s_uv_star"], case["s_uv_star"])
         np.testing.assert_allclose(out["v_c"], case["v_c"], rtol=1e-10)
+
+
+def test_rig8_fixture_pairs_meet_the_acceptance_rule_and_match_the_oracle():
+    """BASELINE.json configs[3] (8-camera rig): 8 accepted ViT-B/16 pairs, pair 0 = the headline fixture's pair."""
+    blob = load_golden("rig8_vitb16_224.npz")
+    seeds = [int(s) for s in blob["frame_seeds"]]
+    assert len(seeds) == 8 and seeds == list(synth.RIG8_FRAME_SEEDS) and seeds[0] == synth.ACCEPTED_FRAME_SEEDS["vitb16_224"]
+    head = golden_case(load_golden("e2e_vitb16_224.npz"), "plain")
+    pair0 = golden_case(blob, "pair0")
+    assert np.array_equal(pair0["nn_1"], head["nn_1"]) and np.array_equal(pair0["v_c"], head["v_c"])
+    cfg = config.baseline_config("vitb16_224")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    p = config.ServoParams(dino_input_size=cfg.img_size)
+    for i in (1, 7):                                   # two of the pairs through the whole oracle (CPU time)
+        case = golden_case(blob, f"pair{i}")
+        assert min(float(case["margin_rows"]), float(case["margin_cols"])) >= 1e-4
+        des, cur = synth.frame_pair(cfg.img_size, seeds[i])
+        toks = vit_ref.block_tokens(sd, np.stack([des, cur]), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
+                                    layer=cfg.layer, mean=cfg.mean, std=cfg.std)[:, 1:]
+        torch.manual_seed(121)
+        out = sr.servo_update(toks[0], toks[1], synth.depth_pattern(), num_pairs=p.num_pairs, input_size=cfg.img_size,
+                              u_max=p.u_max, v_max=p.v_max, fx=p.f_x, fy=p.f_y, lam=p.lambda_)
+        assert np.array_equal(out["corr"]["nn_1"].numpy(), case["nn_1"])
+        assert np.array_equal(out["corr"]["points1"].numpy(), case["points1"])
+        np.testing.assert_allclose(out["v_c"], case["v_c"], rtol=1e-10)
+
+
+def test_rotation_fixture_matches_the_oracle_draws_and_scores():
+    """find_and_set_best_pose (vitvs_v2.py:1151-1189): four views, num_pairs = 48, consecutive draws, mean similarity."""
+    blob = load_golden("rotation_vits16_224.npz")
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    views = [np.rot90(cur, int(k)).copy() for k in blob["rot90_k"]]
+    toks = vit_ref.block_tokens(sd, np.stack([des] + views), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
+                                layer=cfg.layer, mean=cfg.mean, std=cfg.std)[:, 1:]
+    torch.manual_seed(121)
+    scores = []
+    for i in range(4):
+        corr = sr.find_correspondences(toks[0], toks[1 + i], num_pairs=int(blob["num_pairs"]))
+        assert np.array_equal(corr["points1"].numpy(), blob[f"view{i}/points1"])
+        assert np.array_equal(corr["points2"].numpy(), blob[f"view{i}/points2"])
+        scores.append(corr["sim"].mean().item())
+        assert scores[-1] == float(blob[f"view{i}/score"])
+    assert int(np.argmax(scores)) == int(blob["best"]) == 1          # the un-rotated view

@@ -50,6 +50,14 @@ __global__ void k_load_then_fill_rows(const float4* __restrict__ in, float4* __r
     if (i < rows * 8) { float4 v = in[i & 1023]; out[i] = v; }
 }
 
+// holds the queue busy for `us` microseconds (bounded: s_memrealtime ticks at 100 MHz) so that the host can enqueue the
+// whole chain behind it: what follows is the DEVICE-side cost per dependent launch, free of host enqueue time
+__global__ void k_blocker(float* p, unsigned us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+    if (p == nullptr) p[0] = 1.f;
+}
+
 struct Timer {
     std::vector<hipEvent_t> a, b;
     explicit Timer(int n) : a(n), b(n) { for (int i = 0; i < n; ++i) { CHECK(hipEventCreate(&a[i])); CHECK(hipEventCreate(&b[i])); } }
@@ -81,6 +89,44 @@ static void run(const char* name, int reps, hipStream_t st, F launch) {
     printf("%-44s chain %6.2f us/launch   kernel avg %6.2f us  min %6.2f us\n", name, chain_ms * 1e3 / reps, sum * 1e3 / reps, mn * 1e3);
 }
 
+// the same chain enqueued behind a blocker kernel (device-side floor) and replayed as a hipGraph
+template <class F>
+static void run_queued(const char* name, int reps, hipStream_t st, float* buf, F launch) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int round = 0; round < 3; ++round) {
+        hipLaunchKernelGGL(k_blocker, dim3(1), dim3(64), 0, st, buf, 4000u);   // 4 ms: the host enqueues `reps` launches meanwhile
+        CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch(nullptr, nullptr);
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    // graph replay of the same chain
+    hipGraph_t g; hipGraphExec_t ge;
+    CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < reps; ++i) launch(nullptr, nullptr);
+    CHECK(hipStreamEndCapture(st, &g));
+    CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CHECK(hipGraphLaunch(ge, st));
+    CHECK(hipStreamSynchronize(st));
+    float gbest = 1e9f;
+    for (int round = 0; round < 3; ++round) {
+        CHECK(hipEventRecord(e0, st));
+        CHECK(hipGraphLaunch(ge, st));
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < gbest) gbest = ms;
+    }
+    CHECK(hipGraphExecDestroy(ge)); CHECK(hipGraphDestroy(g));
+    printf("%-44s queued behind a blocker %6.2f us/launch   graph replay %6.2f us/launch\n", name, best * 1e3 / reps, gbest * 1e3 / reps);
+}
+
 int main() {
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
@@ -92,6 +138,9 @@ int main() {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int reps = 400;
 #define L(kern, grid, block, lds, ...) [&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(kern, grid, block, lds, st, a, b, 0, __VA_ARGS__); }
+    run_queued("empty 256 x 64", reps, st, (float*)bufa, L(k_empty, dim3(256), dim3(64), 0, (float*)bufa));
+    run_queued("empty 252 x 512", reps, st, (float*)bufa, L(k_empty, dim3(252), dim3(512), 0, (float*)bufa));
+    run_queued("copy 1.2 MB 296 x 256", reps, st, (float*)bufa, L(k_copy, dim3((n4 + 255) / 256), dim3(256), 0, bufa, bufb, n4));
     run("empty 1 x 64", reps, st, L(k_empty, dim3(1), dim3(64), 0, (float*)bufa));
     run("empty 256 x 64", reps, st, L(k_empty, dim3(256), dim3(64), 0, (float*)bufa));
     run("empty 394 x 64", reps, st, L(k_empty, dim3(394), dim3(64), 0, (float*)bufa));

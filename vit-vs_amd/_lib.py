@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITVS_LIB") or os.path.join(_HERE, "libvitvs_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 STATUS_OK, STATUS_NO_CORRESPONDENCE, STATUS_TOO_FEW, STATUS_NO_DEPTH = 0, 1, 2, 3
 SELECT_EXPLICIT, SELECT_ORDER, SELECT_DENSE = 0, 1, 2
@@ -45,12 +45,12 @@ PROTOTYPES = {
     "vitvs_last_error": (C.c_char_p, [_P]),
     "vitvs_set_tensor": (_I, [_P, C.c_char_p, _P, C.c_int64]),
     "vitvs_weights_ready": (_I, [_P]),
-    "vitvs_compute_velocity_dev": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
-    "vitvs_compute_velocity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "vitvs_compute_velocity_dev": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "vitvs_compute_velocity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     "vitvs_extract_descriptors_dev": (_I, [_P, _I, _P, _P, _P]),
     "vitvs_forward_tokens_dev": (_I, [_P, _I, _P, _P, _P]),
     "vitvs_correspond_dev": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "vitvs_servo_from_nn_dev": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "vitvs_servo_from_nn_dev": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "vitvs_last_details": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vitvs_timing_enable": (_I, [_P, _I]),
     "vitvs_timing_classes": (_I, []),

@@ -117,8 +117,14 @@ def vit_config(model_type: str, img_size: int, stride: int | None = None, layer:
         raise ValueError(f"stride {stride} should divide patch_size {patch}")
     if not 0 <= layer < depth:
         raise ValueError(f"layer {layer} outside 0..{depth - 1}")
-    if (img_size - patch) % stride != 0 and img_size < patch:
+    if img_size < patch:
         raise ValueError("image smaller than one patch")
+    if (img_size - patch) % stride != 0:
+        # the reference floors (dinov2_extractor.py:262, 1 + (H - p) // stride) and silently ignores the right / bottom
+        # remainder; the device path needs the covered extent to be exact, so ask for the size that is actually used
+        used = patch + ((img_size - patch) // stride) * stride
+        raise ValueError(f"img_size {img_size} leaves a remainder for patch {patch} / stride {stride}: "
+                         f"resize or crop to {used} (the extent the reference's floor would use)")
     return ViTConfig(model_type=model_type, img_size=int(img_size), patch=patch, stride=stride, dim=dim,
                      depth=depth, heads=heads, layerscale=ls, native_grid=native // patch, layer=layer)
 

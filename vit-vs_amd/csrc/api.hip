@@ -19,6 +19,7 @@ namespace vitvs {
 
 static thread_local std::string g_last_error;
 thread_local LaunchTiming g_launch_timing;
+thread_local int g_current_device = -1;
 
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
@@ -48,9 +49,6 @@ struct Block {
     float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
     float *qkvb = nullptr, *projb = nullptr, *fc1b = nullptr, *fc2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
     void *qkvw = nullptr, *projw = nullptr, *fc1w = nullptr, *fc2w = nullptr;
-    // fused-LayerNorm path: gamma-folded weights and the c1 / c2 epilogue vectors (gemm_fused.hip)
-    void *qkvw_f = nullptr, *fc1w_f = nullptr;
-    float *qkv_c1 = nullptr, *qkv_c2 = nullptr, *fc1_c1 = nullptr, *fc1_c2 = nullptr;
 };
 
 }  // namespace vitvs
@@ -68,15 +66,11 @@ struct vitvs_handle {
     std::string err;
     std::vector<void*> allocs;
     std::map<std::string, bool> have;
-    std::map<std::string, std::vector<float>> stash;   // host copies of the tensors the LayerNorm folding needs
-    bool fused_ln = true, folded = false;
     int desc_keys = -1;   // >= 0 while a velocity update runs: the forward's last launch emits the descriptors and clears this many keys
     bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
     // Pillow-exact resize tables of the last camera frame size (vitvs_resize_frames_dev)
     int rs_h = 0, rs_w = 0, rs_ksx = 0, rs_ksy = 0;
     int *rs_xb = nullptr, *rs_xk = nullptr, *rs_yb = nullptr, *rs_yk = nullptr;
-    void* xb = nullptr;       // residual stream in the GEMM operand type (bf16 mode), [M][D]
-    float* stats = nullptr;   // per-row partial moments [M][D/16][2]
     // weights
     std::vector<Block> blk;
     void* pe_w = nullptr;
@@ -102,20 +96,16 @@ struct vitvs_handle {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;      // class of event pair i (events 2i, 2i+1)
     size_t ev_used = 0;
-    // captured hipGraphs of compute_velocity_dev, keyed on the argument tuple
+    // captured hipGraphs of compute_velocity_dev (opt-in, VITVS_GRAPH=1), keyed on the argument tuple
     struct GraphEntry {
         std::vector<uintptr_t> key;
-        hipGraph_t graph[3] = {nullptr, nullptr, nullptr};      // chain A, chain B, tail
-        hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
         uint64_t last_use = 0;
     };
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
-    bool use_graphs = true;
-    // second launch chain (see forward())
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool two_chains = true;
+    bool use_graphs = false;
 };
 
 namespace {
@@ -125,6 +115,23 @@ int set_err(vitvs_handle* h, int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+
+// Every entry point that takes a handle runs on the handle's device, whatever device the calling thread had current
+// (include/vitvs.h: "a handle is bound to the HIP device that was current when it was created"); the caller's device is
+// restored on return.  The pointer-only operator hooks (vitvs_op_*) run on the caller's current device.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(const vitvs_handle* h) {
+        (void)hipGetDevice(&prev);
+        const int want = h ? h->device : prev;
+        if (want != prev) switched = hipSetDevice(want) == hipSuccess;
+        g_current_device = switched ? want : prev;
+    }
+    ~DeviceScope() {
+        if (switched) { (void)hipSetDevice(prev); g_current_device = prev; }
+    }
+};
 
 template <typename T>
 int dev_alloc(vitvs_handle* h, T** out, size_t count) {
@@ -187,47 +194,6 @@ int check_cfg(const vitvs_config* c, std::string& why) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// W'[n][k] = gamma[k] W[n][k] (uploaded in the operand type), c1[n] = sum_k W'[n][k] as the GEMM will see it
-// (after rounding to the operand type), c2[n] = sum_k beta[k] W[n][k] + bias[n].  See gemm_fused.hip.
-int fold_one(vitvs_handle* h, const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& gamma,
-             const std::vector<float>& beta, size_t N, size_t K, void** wf, float** c1, float** c2) {
-    std::vector<float> Wf(N * K), v1(N), v2(N);
-    for (size_t n = 0; n < N; ++n) {
-        double s1 = 0.0, s2 = 0.0;
-        for (size_t k = 0; k < K; ++k) {
-            float w = W[n * K + k] * gamma[k];
-            Wf[n * K + k] = w;
-            if (h->prec == PREC_BF16) {
-                const uint32_t bits = (uint32_t)f32_to_bf16_host(w) << 16;
-                memcpy(&w, &bits, 4);
-            }
-            s1 += (double)w;
-            s2 += (double)beta[k] * (double)W[n * K + k];
-        }
-        v1[n] = (float)s1;
-        v2[n] = (float)(s2 + (double)bias[n]);
-    }
-    int rc = upload_matrix(h, wf, Wf.data(), N, K, K);
-    if (!rc) rc = upload_f32(h, c1, v1.data(), N);
-    if (!rc) rc = upload_f32(h, c2, v2.data(), N);
-    return rc;
-}
-
-int fold_layernorms(vitvs_handle* h) {
-    const size_t D = h->cfg.dim, H4 = h->hidden;
-    for (int i = 0; i < h->cfg.blocks; ++i) {
-        const std::string b = "blocks." + std::to_string(i) + ".";
-        Block& blk = h->blk[i];
-        int rc = fold_one(h, h->stash[b + "attn.qkv.weight"], h->stash[b + "attn.qkv.bias"], h->stash[b + "norm1.weight"],
-                          h->stash[b + "norm1.bias"], 3 * D, D, &blk.qkvw_f, &blk.qkv_c1, &blk.qkv_c2);
-        if (!rc)
-            rc = fold_one(h, h->stash[b + "mlp.fc1.weight"], h->stash[b + "mlp.fc1.bias"], h->stash[b + "norm2.weight"],
-                          h->stash[b + "norm2.bias"], H4, D, &blk.fc1w_f, &blk.fc1_c1, &blk.fc1_c2);
-        if (rc) return set_err(h, rc, "LayerNorm folding failed for block " + std::to_string(i));
-    }
-    return 0;
-}
-
 enum KernelClass : int {
     KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
     KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_COUNT
@@ -266,7 +232,7 @@ struct Span {
 
 // One launch chain's view of the workspaces (a contiguous range of images).
 // Plain descriptors of the default forward are produced by the forward's own last launch.
-static bool desc_in_forward(const vitvs_handle* h) { return !h->cfg.binned && !h->fused_ln && h->Dp == h->cfg.dim; }
+static bool desc_in_forward(const vitvs_handle* h) { return !h->cfg.binned && h->Dp == h->cfg.dim; }
 
 struct ChainCtx {
     int cnt = 0, M = 0;
@@ -278,10 +244,9 @@ struct ChainCtx {
     DescOut desc;
 };
 
-// The default (split-K + residual_ln) forward, operator by operator, for n chains on one stream (n = 1 in
-// production).  n = 2 with the second chain's launches flagged hipExtAnyOrderLaunch (no AQL barrier bit) was
-// tried to overlap the two frames inside one queue: gfx9 ignores the flag (hip_ext.h says so, and the update
-// took 0.90 ms instead of 0.53 ms), so kernels of one update cannot overlap on this platform.
+// The forward, operator by operator, on one stream.  (Two chains — the two frames on two streams, or in lockstep on one
+// stream with hipExtAnyOrderLaunch — were measured in round 1: kernels of different queues alternate instead of
+// overlapping on this platform and gfx9 ignores the any-order flag, so the code was removed: profiles/r01_notes.md.)
 int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     const vitvs_config& c = h->cfg;
     const int D = c.dim;
@@ -347,7 +312,6 @@ ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     pa.S = c.img_size; pa.patch = c.patch; pa.stride = c.stride; pa.grid = h->grid; pa.Kp = h->Kp; pa.D = D;
     for (int i = 0; i < 3; ++i) { pa.mean[i] = c.mean[i]; pa.std[i] = c.std[i]; }
     pa.cls = h->cls; pa.pos = h->pos;
-    pa.xb = nullptr; pa.stats = nullptr;
     return cx;
 }
 
@@ -355,39 +319,7 @@ ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
 // frames) on stream `st`: an independent chain of launches touching only those images' rows.
 int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part,
                   hipStream_t st) {
-    const vitvs_config& c = h->cfg;
     ChainCtx cx = fill_ctx(h, i0, cnt, n_des, des, cur, part);
-    if (h->fused_ln) {
-        // opt-in: 5 launches per block, the LayerNorms live in the GEMM epilogues (gemm_fused.hip)
-        const int M = cx.M, D = c.dim;
-        const size_t row0 = (size_t)i0 * h->N;
-        unsigned char* xb = (h->prec == PREC_BF16) ? (unsigned char*)h->xb + row0 * D * elem_size(h->prec) : nullptr;
-        float* stats = h->stats + row0 * (D / 16) * 2;
-        const void* a_op = xb ? (const void*)xb : (const void*)cx.x;   // operand of the qkv / fc1 GEMMs
-        cx.pa.xb = xb; cx.pa.stats = stats;
-        int rc;
-        { Span sp(h, KC_PATCHIFY, st); rc = launch_patchify(h->prec, cx.pa, cx.Ape, cx.x, st); }
-        if (rc) return set_err(h, rc, "patchify launch failed");
-        { Span sp(h, KC_PATCH_EMBED, st);
-          rc = launch_patch_embed_stats(h->prec, cx.Ape, h->pe_w, h->pe_b, h->pos, cx.x, xb, stats, cnt, h->T, D, h->Kp, st); }
-        if (rc) return set_err(h, rc, "patch-embed launch failed");
-        for (int i = 0; i < c.blocks; ++i) {
-            const Block& b = h->blk[i];
-            { Span sp(h, KC_QKV, st);
-              rc = launch_linear_ln(h->prec, a_op, b.qkvw_f, b.qkv_c1, b.qkv_c2, stats, D, cx.qkv, M, 3 * D, D, 0, c.ln_eps, st); }
-            if (!rc) { Span sp(h, KC_ATTENTION, st); rc = launch_attention(h->prec, cx.qkv, cx.attn, cnt, h->N, c.heads, st); }
-            if (!rc) { Span sp(h, KC_PROJ, st);
-                       rc = launch_linear_residual_stats(h->prec, cx.attn, b.projw, b.projb, b.ls1, cx.x, xb, stats, M, D, D, st); }
-            if (!rc) { Span sp(h, KC_FC1, st);
-                       rc = launch_linear_ln(h->prec, a_op, b.fc1w_f, b.fc1_c1, b.fc1_c2, stats, D, cx.hid, M, h->hidden, D, 1,
-                                             c.ln_eps, st); }
-            if (!rc) { Span sp(h, KC_FC2, st);
-                       rc = launch_linear_residual_stats(h->prec, cx.hid, b.fc2w, b.fc2b, b.ls2, cx.x, xb, stats, M, D, h->hidden,
-                                                         st); }
-            if (rc) return set_err(h, rc, "block launch failed");
-        }
-        return 0;
-    }
     if (h->desc_keys >= 0 && desc_in_forward(h)) {
         cx.want_desc = true;
         cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
@@ -398,30 +330,21 @@ int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     return forward_lockstep(h, &cx, 1, st);
 }
 
-// The images of one call are independent until the correspondence stage, and at one frame pair each
-// launch fills well under half of the chip, so the image list is cut in two chains that run
-// concurrently: the first half on the caller's stream, the second on the handle's side stream
-// (fork / join with events; inside a stream capture this becomes two parallel branches of the graph).
 int forward(vitvs_handle* h, int n_des, const uint8_t* des, int n_cur, const uint8_t* cur, hipStream_t st) {
     const int n_img = n_des + n_cur;
     if (n_img <= 0 || n_img > h->n_img_max) return set_err(h, -3, "frame count exceeds the handle's capacity");
     if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
-    const size_t part_half = (size_t)8 * (h->n_img_max / 2 + 1) * h->N * h->cfg.dim;
-    if (n_img == 1 || !h->two_chains)
-        return forward_chain(h, 0, n_img, n_des, des, cur, h->part, st);
-    const int first = n_img / 2;
-    VITVS_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-    VITVS_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    int rc = forward_chain(h, 0, first, n_des, des, cur, h->part, st);
-    int rc2 = forward_chain(h, first, n_img - first, n_des, des, cur, h->part + part_half, h->side);
-    VITVS_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
-    VITVS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
-    return rc ? rc : rc2;
+    return forward_chain(h, 0, n_img, n_des, des, cur, h->part, st);
 }
 
-int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const double* K, int mode,
+// num_pairs of one call: <= 0 means the handle's default (cfg.num_pairs); the reference changes it per call site
+// (24 in the servo loop, 48 in the rotation search, vitvs_v2.py:1151-1189), so it is a per-call argument.
+int call_num_pairs(const vitvs_handle* h, int32_t num_pairs) { return num_pairs > 0 ? num_pairs : h->cfg.num_pairs; }
+
+int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const double* K, int mode, int num_pairs,
               const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status, hipStream_t st) {
     const vitvs_config& c = h->cfg;
+    if (num_pairs <= 0 || num_pairs > c.max_rows) return set_err(h, -5, "num_pairs must be in 1 .. max_rows");
     const int g = (int)floor(sqrt((double)T));  // reference: int(np.sqrt(T)), vitvs_v2.py:75
     if (g * g != T) return set_err(h, -5, "token count is not a square grid");
     if (mode < 0 || mode > 2) return set_err(h, -5, "unknown selection mode");
@@ -430,7 +353,7 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     if (mode == VITVS_SELECT_DENSE && c.max_rows < T) return set_err(h, -5, "DENSE selection needs max_rows >= T");
     ServoArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_pairs = n_pairs; a.T = T; a.grid = g; a.num_pairs = c.num_pairs; a.mode = mode;
+    a.n_pairs = n_pairs; a.T = T; a.grid = g; a.num_pairs = num_pairs; a.mode = mode;
     a.input_size = c.img_size; a.u_max = c.u_max; a.v_max = c.v_max; a.depth_h = c.v_max; a.depth_w = c.u_max;
     const double scale = (double)c.img_size / (double)g;                 // vitvs_v2.py:511
     a.scale_f = (float)scale; a.half_f = (float)(scale / 2.0);
@@ -439,7 +362,7 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     a.K = K; a.lambda = c.lambda;
     a.row_best = h->row_best; a.col_best = h->col_best; a.depth = Z;
     a.selection = selection; a.n_selected = n_selected;
-    a.sel_stride = (mode == VITVS_SELECT_EXPLICIT) ? c.num_pairs : T;
+    a.sel_stride = (mode == VITVS_SELECT_EXPLICIT) ? num_pairs : T;
     a.v_c = v_c; a.status = status; a.nn1 = h->nn1; a.nn2 = h->nn2; a.sim1 = h->sim1; a.info = h->info;
     a.sel_out = h->sel_out; a.s_uv = h->s_uv; a.feat = h->feat; a.L_ws = h->Lws; a.max_rows = c.max_rows;
     h->last_pairs = n_pairs; h->last_T = T;
@@ -474,6 +397,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->cfg = *cfg;
     h->prec = to_prec(cfg->precision);
     (void)hipGetDevice(&h->device);
+    g_current_device = h->device;
     h->grid = 1 + (cfg->img_size - cfg->patch) / cfg->stride;
     h->T = h->grid * h->grid;
     h->N = h->T + 1;
@@ -483,33 +407,12 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->hidden = 4 * cfg->dim;
     h->n_img_max = 2 * cfg->max_pairs;
     h->blk.resize(cfg->blocks);
-    // hipGraph replay of the update is opt-in: with kernel arguments in device memory
-    // (HIP_FORCE_DEV_KERNARG=1, set by the Python package before HIP initialises) plain stream launches
-    // measured 2 % FASTER than replaying the captured graph (554 vs 567 us per update), and 18 % slower
-    // than it with host-memory kernargs.
+    // hipGraph replay of the update is opt-in (VITVS_GRAPH=1, read once per handle): with kernel arguments in device
+    // memory (HIP_FORCE_DEV_KERNARG=1, set by the Python package before HIP initialises) plain stream launches measured
+    // 2 % FASTER than replaying the captured graph; the graph's use is a caller whose host thread cannot spare the
+    // ~0.35 ms of launch calls per update.
     const char* ng = getenv("VITVS_GRAPH");
     h->use_graphs = (ng && ng[0] == '1');
-    const char* nc = getenv("VITVS_ONE_CHAIN");
-    // Off by default: on this platform kernels of different queues were measured to alternate rather
-    // than overlap (rocprofv3 timeline, profiles/), so the second chain only adds fork/join cost.
-    // LayerNorm folded into the GEMM epilogues (5 launches per block instead of 7, gemm_fused.hip): correct
-    // and tested, but measured 3-6 % slower at one frame pair (the 84-workgroup fc2 without split-K and the
-    // moment merge in the consumers cost more than the two residual_ln launches save) -> opt-in.
-    const char* fl = getenv("VITVS_FUSED_LN");
-    h->fused_ln = (fl && fl[0] == '1') && h->prec != PREC_F16;   // the opt-in fused-LayerNorm GEMMs exist for fp32 / bf16
-    const char* tc = getenv("VITVS_TWO_CHAINS");
-    (void)nc;
-    h->two_chains = (tc && tc[0] == '1');
-    // A different priority class gives the side stream a hardware queue of its own (streams of one
-    // priority can share a queue, which would serialise the two chains).
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-        delete h;
-        return set_err(nullptr, -2, "could not create the side stream / events");
-    }
     const size_t M = (size_t)h->n_img_max * h->N, D = cfg->dim, es = elem_size(h->prec);
     int rc = 0;
     unsigned char* p8 = nullptr;
@@ -522,9 +425,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     ALLOC_BYTES(hid, M * h->hidden * es);
 #undef ALLOC_BYTES
     if (!rc) rc = dev_alloc(h, &h->x, M * D);
-    if (!rc) rc = dev_alloc(h, &h->part, 2 * (size_t)8 * (h->n_img_max / 2 + 1) * h->N * D);
-    if (!rc) { rc = dev_alloc(h, &p8, M * D * es); h->xb = p8; }
-    if (!rc) rc = dev_alloc(h, &h->stats, M * (D / 16) * 2);
+    if (!rc) rc = dev_alloc(h, &h->part, (size_t)8 * M * D);   // at most 8 split-K slices (splitk_slices)
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
@@ -546,7 +447,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     if (!rc) rc = dev_alloc(h, &h->st_depth, P * (size_t)cfg->u_max * cfg->v_max);
     if (!rc) rc = dev_alloc(h, &h->st_K, P * 4);
     if (!rc) rc = dev_alloc(h, &h->st_vc, P * 6);
-    const size_t sel_cap = P * (size_t)(h->T > cfg->num_pairs ? h->T : cfg->num_pairs);
+    const size_t sel_cap = P * (size_t)(h->T > cfg->max_rows ? h->T : cfg->max_rows);
     if (!rc) rc = dev_alloc(h, &h->st_sel, sel_cap);
     if (!rc) rc = dev_alloc(h, &h->st_nsel, P);
     if (!rc) rc = dev_alloc(h, &h->st_status, P);
@@ -561,21 +462,19 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 
 void vitvs_destroy(vitvs_handle* h) {
     if (!h) return;
-    for (auto& g : h->graphs)
-        for (int k = 0; k < 3; ++k) {
-            if (g.exec[k]) (void)hipGraphExecDestroy(g.exec[k]);
-            if (g.graph[k]) (void)hipGraphDestroy(g.graph[k]);
-        }
+    DeviceScope dev(h);
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->side) (void)hipStreamDestroy(h->side);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
 
 int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64_t numel) {
     if (!h || !name || !data) return set_err(h, -1, "null argument");
+    DeviceScope dev(h);
     const vitvs_config& c = h->cfg;
     const size_t D = c.dim, H4 = h->hidden;
     const std::string nm(name);
@@ -628,15 +527,6 @@ int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64
     if (rc == 0) {
         h->have[nm] = true;
         h->ready = false;
-        const size_t dot2 = nm.rfind("blocks.", 0) == 0 ? nm.find('.', 7) : std::string::npos;
-        if (dot2 != std::string::npos) {
-            const std::string leaf = nm.substr(dot2 + 1);
-            if (leaf == "norm1.weight" || leaf == "norm1.bias" || leaf == "norm2.weight" || leaf == "norm2.bias" ||
-                leaf == "attn.qkv.weight" || leaf == "attn.qkv.bias" || leaf == "mlp.fc1.weight" || leaf == "mlp.fc1.bias") {
-                h->stash[nm].assign(data, data + numel);
-                h->folded = false;
-            }
-        }
     }
     return rc;
 }
@@ -661,17 +551,13 @@ int vitvs_weights_ready(const vitvs_handle* hc) {
             h->err = "missing tensor " + n;
             return -4;
         }
-    if (h->fused_ln && !h->folded) {
-        int rc = fold_layernorms(h);
-        if (rc) return rc;
-        h->folded = true;
-    }
     h->ready = true;
     return 0;
 }
 
 int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream) {
     if (!h || !frames || !tokens) return set_err(h, -1, "null argument");
+    DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);
     if (rc) return rc;
@@ -693,10 +579,11 @@ int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* fr
                             uint8_t* out, void* stream) {
     if (!h || !frames || !out) return set_err(h, -1, "null argument");
     if (n_frames <= 0 || in_h <= 0 || in_w <= 0) return set_err(h, -5, "bad frame geometry");
+    DeviceScope dev(h);
     if (in_h != h->rs_h || in_w != h->rs_w) {   // new camera resolution: build the coefficient tables (synchronises once)
         for (int** t : {&h->rs_xb, &h->rs_xk, &h->rs_yb, &h->rs_yk}) {   // drop the previous resolution's tables
             if (*t) {
-                VITVS_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+                VITVS_HIP_CHECK(hipDeviceSynchronize());   // a resize launched on ANY stream may still read them
                 h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*t), h->allocs.end());
                 (void)hipFree(*t);
                 *t = nullptr;
@@ -718,6 +605,7 @@ int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* fr
 
 int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* desc, void* stream) {
     if (!h || !frames || !desc) return set_err(h, -1, "null argument");
+    DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);
     if (rc) return rc;
@@ -730,6 +618,7 @@ int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* fr
                             void* stream) {
     if (!h || !frames || !desc) return set_err(h, -1, "null argument");
     if (facet < 0 || facet > 2) return set_err(h, -5, "facet must be 0 (query), 1 (key) or 2 (value)");
+    DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
     if (rc) return rc;
@@ -744,6 +633,7 @@ int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* de
     if (T <= 0 || Dp <= 0 || Dp % 32 != 0) return set_err(h, -5, "Dp must be a positive multiple of 32");
     if ((size_t)2 * T * Dp > h->dn_elems || (size_t)T > h->best_elems)
         return set_err(h, -3, "descriptors exceed the handle's workspace");
+    DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = launch_normalize_rows(desc1, h->dn, T, Dp, st);
     if (!rc) rc = launch_normalize_rows(desc2, h->dn + (size_t)T * Dp, T, Dp, st);
@@ -759,21 +649,21 @@ int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* de
 
 int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, const int32_t* nn_2, const float* sim_1,
                             const uint16_t* Z_mm, const double* K, int32_t select_mode, const int32_t* selection,
-                            int32_t n_selected, double* v_c, int32_t* status, void* stream) {
+                            int32_t n_selected, int32_t num_pairs, double* v_c, int32_t* status, void* stream) {
     if (!h || !nn_1 || !nn_2 || !sim_1 || !K || !v_c || !status) return set_err(h, -1, "null argument");
     if ((size_t)T > h->best_elems) return set_err(h, -3, "T exceeds the handle's workspace");
+    DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = launch_encode_best(nn_1, nn_2, sim_1, T, h->row_best, h->col_best, st);
     if (rc) return set_err(h, rc, "encode launch failed");
     VITVS_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->st_nsel), n_selected, 1, st));
-    return run_servo(h, 1, T, Z_mm, K, select_mode, selection, h->st_nsel, v_c, status, st);
+    return run_servo(h, 1, T, Z_mm, K, select_mode, call_num_pairs(h, num_pairs), selection, h->st_nsel, v_c, status, st);
 }
 
-// The update is three launch segments: forward of the first half of the image list (A, caller's
-// stream), forward of the second half (B, side stream, concurrent with A) and the tail
-// (descriptors, Gram + argmax, control law) after the join.
+// One update = forward of the call's image list (desired frames first, then current frames) + the tail
+// (descriptors when binned, Gram + arg-max, control law), all on the caller's stream.
 struct UpdateArgs {
-    int32_t n_pairs, des_shared, select_mode;
+    int32_t n_pairs, des_shared, select_mode, num_pairs;
     const uint8_t *I_cur, *I_des;
     const uint16_t* Z_mm;
     const double* K;
@@ -782,133 +672,105 @@ struct UpdateArgs {
     int32_t* status;
 };
 
-static int segment_forward(vitvs_handle* h, const UpdateArgs& u, int which, hipStream_t st) {
+static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
-    const int first = h->two_chains ? n_img / 2 : n_img;
-    const size_t part_half = (size_t)8 * (h->n_img_max / 2 + 1) * h->N * h->cfg.dim;
     h->desc_keys = u.n_pairs * h->T;
-    int rc = 0;
-    if (which == 0) rc = forward_chain(h, 0, first, n_des, u.I_des, u.I_cur, h->part, st);
-    else if (first != n_img) rc = forward_chain(h, first, n_img - first, n_des, u.I_des, u.I_cur, h->part + part_half, st);
+    int rc = forward_chain(h, 0, n_img, n_des, u.I_des, u.I_cur, h->part, st);
     h->desc_keys = -1;
-    return rc;
-}
-
-static int segment_tail(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
-    const int n_des = u.des_shared ? 1 : u.n_pairs;
-    int rc;
+    if (rc) return rc;
     if (!desc_in_forward(h)) {
         Span sp(h, KC_DESCRIPTORS, st);
-        rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_des + u.n_pairs, h->T, h->grid, h->cfg.dim, h->cfg.binned,
+        rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_img, h->T, h->grid, h->cfg.dim, h->cfg.binned,
                                 h->row_best, h->col_best, u.n_pairs * h->T, st);
         if (rc) return set_err(h, rc, "descriptor launch failed");
     }
     { Span sp(h, KC_GRAM, st);
       rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");
-    rc = run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.selection, u.n_selected, u.v_c, u.status, st);
-    return rc;
+    return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.num_pairs, u.selection, u.n_selected, u.v_c,
+                     u.status, st);
 }
 
-static int capture_segment(vitvs_handle* h, hipStream_t st, hipGraphExec_t* exec, hipGraph_t* graph, int rc_launch_dummy,
-                           const UpdateArgs& u, int which) {
-    (void)rc_launch_dummy;
-    VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = (which < 2) ? segment_forward(h, u, which, st) : segment_tail(h, u, st);
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(st, &g);
-    if (rc) {
-        if (g) (void)hipGraphDestroy(g);
-        return rc;
+// VITVS_GRAPH=1: the update is captured once per argument tuple and replayed.  The selection array is the one argument
+// a control loop changes every update (a fresh visiting order), so it is not part of the key: the graph reads the
+// handle's own copy (st_sel / st_nsel), refreshed by two small device-to-device copies ahead of each replay.
+static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
+    const size_t sel_elems = u.select_mode == VITVS_SELECT_EXPLICIT ? (size_t)u.n_pairs * u.num_pairs
+                             : (u.select_mode == VITVS_SELECT_ORDER ? (size_t)u.n_pairs * h->T : 0);
+    if (sel_elems && u.selection && u.selection != h->st_sel)
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, u.selection, sel_elems * 4, hipMemcpyDeviceToDevice, st));
+    if (u.select_mode == VITVS_SELECT_EXPLICIT && u.n_selected && u.n_selected != h->st_nsel)
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, u.n_selected, (size_t)u.n_pairs * 4, hipMemcpyDeviceToDevice, st));
+    if (u.selection) u.selection = h->st_sel;
+    if (u.n_selected) u.n_selected = h->st_nsel;
+    const std::vector<uintptr_t> key = {(uintptr_t)u.n_pairs, (uintptr_t)u.I_cur, (uintptr_t)u.I_des, (uintptr_t)u.des_shared,
+                                        (uintptr_t)u.Z_mm, (uintptr_t)u.K, (uintptr_t)u.select_mode, (uintptr_t)u.num_pairs,
+                                        (uintptr_t)(u.selection != nullptr), (uintptr_t)(u.n_selected != nullptr),
+                                        (uintptr_t)u.v_c, (uintptr_t)u.status};
+    vitvs_handle::GraphEntry* ge = nullptr;
+    for (auto& g : h->graphs)
+        if (g.key == key) ge = &g;
+    if (!ge) {
+        if (h->graphs.size() >= 8) {  // evict the least recently used entry
+            size_t victim = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i)
+                if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
+            if (h->graphs[victim].exec) (void)hipGraphExecDestroy(h->graphs[victim].exec);
+            if (h->graphs[victim].graph) (void)hipGraphDestroy(h->graphs[victim].graph);
+            h->graphs.erase(h->graphs.begin() + victim);
+        }
+        vitvs_handle::GraphEntry fresh;
+        fresh.key = key;
+        VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_update(h, u, st);
+        hipError_t e = hipStreamEndCapture(st, &fresh.graph);
+        if (rc) {
+            if (fresh.graph) (void)hipGraphDestroy(fresh.graph);
+            return rc;
+        }
+        if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __FILE__, __LINE__);
+        e = hipGraphInstantiate(&fresh.exec, fresh.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(fresh.graph);
+            return fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
+        }
+        h->graphs.push_back(fresh);
+        ge = &h->graphs.back();
     }
-    if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __FILE__, __LINE__);
-    e = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        return fail_hip(e, "hipGraphInstantiate", __FILE__, __LINE__);
-    }
-    *graph = g;
+    ge->last_use = ++h->graph_clock;
+    h->last_pairs = u.n_pairs; h->last_T = h->T;
+    VITVS_HIP_CHECK(hipGraphLaunch(ge->exec, st));
     return 0;
 }
 
 int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                                int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
-                               const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status,
-                               void* stream) {
+                               const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
+                               int32_t* status, void* stream) {
     if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
+    const int np = call_num_pairs(h, num_pairs);
+    if (np > h->cfg.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
+    if (select_mode != VITVS_SELECT_DENSE && !selection) return set_err(h, -5, "selection array required for this mode");
+    if (select_mode == VITVS_SELECT_EXPLICIT && !n_selected) return set_err(h, -5, "n_selected required for EXPLICIT");
+    DeviceScope dev(h);
     if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
     hipStream_t st = as_stream(stream);
-    UpdateArgs u{n_pairs, des_shared, select_mode, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
-    const bool graphs = h->use_graphs && !h->timing && st != nullptr;
-    vitvs_handle::GraphEntry* ge = nullptr;
-    if (graphs) {
-        std::vector<uintptr_t> key = {(uintptr_t)n_pairs, (uintptr_t)I_cur, (uintptr_t)I_des, (uintptr_t)des_shared,
-                                      (uintptr_t)Z_mm, (uintptr_t)K, (uintptr_t)select_mode, (uintptr_t)selection,
-                                      (uintptr_t)n_selected, (uintptr_t)v_c, (uintptr_t)status};
-        for (auto& g : h->graphs)
-            if (g.key == key) ge = &g;
-        if (!ge) {
-            if (h->graphs.size() >= 8) {  // evict the least recently used entry
-                size_t victim = 0;
-                for (size_t i = 1; i < h->graphs.size(); ++i)
-                    if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
-                for (int k = 0; k < 3; ++k) {
-                    if (h->graphs[victim].exec[k]) (void)hipGraphExecDestroy(h->graphs[victim].exec[k]);
-                    if (h->graphs[victim].graph[k]) (void)hipGraphDestroy(h->graphs[victim].graph[k]);
-                }
-                h->graphs.erase(h->graphs.begin() + victim);
-            }
-            vitvs_handle::GraphEntry fresh;
-            fresh.key = key;
-            int rc = capture_segment(h, st, &fresh.exec[0], &fresh.graph[0], 0, u, 0);
-            if (!rc && h->two_chains) rc = capture_segment(h, h->side, &fresh.exec[1], &fresh.graph[1], 0, u, 1);
-            if (!rc) rc = capture_segment(h, st, &fresh.exec[2], &fresh.graph[2], 0, u, 2);
-            if (rc) {
-                for (int k = 0; k < 3; ++k) {
-                    if (fresh.exec[k]) (void)hipGraphExecDestroy(fresh.exec[k]);
-                    if (fresh.graph[k]) (void)hipGraphDestroy(fresh.graph[k]);
-                }
-                return rc;
-            }
-            h->graphs.push_back(fresh);
-            ge = &h->graphs.back();
-        }
-        ge->last_use = ++h->graph_clock;
-    }
-    // fork: the side stream starts after everything already queued on the caller's stream
-    const bool fork = h->two_chains;
-    if (fork) {
-        VITVS_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-        VITVS_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    }
-    int rc = 0;
-    if (ge) {
-        VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[0], st));
-        if (fork) VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[1], h->side));
-    } else {
-        rc = segment_forward(h, u, 0, st);
-        if (!rc && fork) rc = segment_forward(h, u, 1, h->side);
-    }
-    if (fork) {
-        VITVS_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
-        VITVS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
-    }
-    if (rc) return rc;
-    if (ge) {
-        h->last_pairs = n_pairs; h->last_T = h->T;
-        VITVS_HIP_CHECK(hipGraphLaunch(ge->exec[2], st));
-        return 0;
-    }
-    return segment_tail(h, u, st);
+    const UpdateArgs u{n_pairs, des_shared, select_mode, np, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
+    if (h->use_graphs && !h->timing && st != nullptr) return replay_update(h, u, st);
+    return enqueue_update(h, u, st);
 }
 
 int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
-                           const int32_t* selection, const int32_t* n_selected, double* v_c, int32_t* status) {
+                           const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
+                           int32_t* status) {
     if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
     const vitvs_config& c = h->cfg;
+    const int np = call_num_pairs(h, num_pairs);
+    if (np > c.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
+    DeviceScope dev(h);
     const size_t img = (size_t)c.img_size * c.img_size * 3;
     hipStream_t st = nullptr;
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_cur, I_cur, n_pairs * img, hipMemcpyHostToDevice, st));
@@ -918,14 +780,14 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_K, K, (size_t)n_pairs * 4 * sizeof(double), hipMemcpyHostToDevice, st));
     if (select_mode == VITVS_SELECT_EXPLICIT) {
         if (!selection || !n_selected) return set_err(h, -5, "EXPLICIT selection needs ids and counts");
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * c.num_pairs * 4, hipMemcpyHostToDevice, st));
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * np * 4, hipMemcpyHostToDevice, st));
         VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, n_selected, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
     } else if (select_mode == VITVS_SELECT_ORDER) {
         if (!selection) return set_err(h, -5, "ORDER selection needs a visiting order");
         VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * h->T * 4, hipMemcpyHostToDevice, st));
     }
     int rc = vitvs_compute_velocity_dev(h, n_pairs, h->st_cur, h->st_des, des_shared, Z_mm ? h->st_depth : nullptr,
-                                        h->st_K, select_mode, h->st_sel, h->st_nsel, h->st_vc, h->st_status, st);
+                                        h->st_K, select_mode, h->st_sel, h->st_nsel, np, h->st_vc, h->st_status, st);
     if (rc) return rc;
     VITVS_HIP_CHECK(hipMemcpyAsync(v_c, h->st_vc, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     VITVS_HIP_CHECK(hipMemcpyAsync(status, h->st_status, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
@@ -937,6 +799,7 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
                        int32_t* selected, int32_t* s_uv, double* feat, double* L) {
     if (!h) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->last_pairs) return set_err(h, -3, "no such pairs in the last call");
+    DeviceScope dev(h);
     VITVS_HIP_CHECK(hipDeviceSynchronize());
     const size_t T = h->last_T, R = h->cfg.max_rows, P = n_pairs;
     if (nn_1) VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
@@ -952,6 +815,7 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
 
 int vitvs_timing_enable(vitvs_handle* h, int32_t on) {
     if (!h) return set_err(h, -1, "null argument");
+    DeviceScope dev(h);
     VITVS_HIP_CHECK(hipDeviceSynchronize());
     h->timing = on != 0;
     h->ev_used = 0;
@@ -965,6 +829,7 @@ const char* vitvs_timing_class_name(int32_t cls) { return (cls >= 0 && cls < KC_
 
 int vitvs_timing_collect(vitvs_handle* h, int32_t n_classes, double* total_ms, int32_t* launches) {
     if (!h || !total_ms || !launches || n_classes < KC_COUNT) return set_err(h, -1, "bad argument");
+    DeviceScope dev(h);
     VITVS_HIP_CHECK(hipDeviceSynchronize());
     for (int i = 0; i < n_classes; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
     for (size_t i = 0; i < h->ev_class.size(); ++i) {
@@ -981,18 +846,22 @@ int vitvs_timing_collect(vitvs_handle* h, int32_t n_classes, double* total_ms, i
 // ---- include/vitvs_ops.h: single-operator entry points for the kernel-level parity tests ----
 int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float* bias, void* out, int32_t M,
                     int32_t N, int32_t K, int32_t gelu, void* stream) {
+    DeviceScope dev(nullptr);
     return launch_linear(to_prec(precision), A, W, bias, out, M, N, K, gelu, as_stream(stream));
 }
 int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
                              float* x, int32_t M, int32_t N, int32_t K, void* stream) {
+    DeviceScope dev(nullptr);
     return launch_linear_residual(to_prec(precision), A, W, bias, ls, x, M, N, K, as_stream(stream));
 }
 int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
                        int32_t D, float eps, void* stream) {
+    DeviceScope dev(nullptr);
     return launch_layernorm(to_prec(precision), x, gamma, beta, out, M, D, eps, as_stream(stream));
 }
 int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
                        void* stream) {
+    DeviceScope dev(nullptr);
     return launch_attention(to_prec(precision), qkv, out, n_img, N, H, as_stream(stream));
 }
 int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
@@ -1000,11 +869,13 @@ int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
 }
 int vitvs_op_linear_partial(int32_t precision, const void* A, const void* W, float* part, int32_t M, int32_t N,
                             int32_t K, int32_t slices, void* stream) {
+    DeviceScope dev(nullptr);
     return launch_linear_partial(to_prec(precision), A, W, part, M, N, K, slices, as_stream(stream));
 }
 int vitvs_op_residual_ln(int32_t precision, float* x, const float* part, int32_t slices, const float* bias,
                          const float* ls, const float* gamma, const float* beta, void* out, int32_t M, int32_t D,
                          float eps, void* stream) {
+    DeviceScope dev(nullptr);
     return launch_residual_ln(to_prec(precision), x, part, slices, bias, ls, gamma, beta, out, M, D,
                               eps, as_stream(stream));
 }

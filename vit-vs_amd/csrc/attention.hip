@@ -457,16 +457,14 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 }
 
 template <typename HT>
-static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream, bool no_short, bool ks4) {
+static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream) {
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
-    if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32) && !no_short) {
+    if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32)) {
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
                out, N, D, n_img);
-    } else if ((long)nt * H * n_img <= 256 && nt >= 4 && ks4) {
-        launch((attention_16_kernel<HT, 4>), grid, dim3(1024), 4 * 2 * 64 * 128, stream, qkv, out, N, D);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
     } else {
@@ -476,17 +474,15 @@ static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H,
 
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
-    static const bool no_short = getenv("VITVS_ATTN_NO_SHORT") != nullptr;   // experiment switches, read once
-    static const bool ks4 = getenv("VITVS_ATTN_KS4") != nullptr;
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (p == PREC_F16) {
-        launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, no_short, ks4);
+        launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream);
     } else {
-        launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream, no_short, ks4);
+        launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

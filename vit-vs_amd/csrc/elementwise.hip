@@ -20,29 +20,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
         const int img = row - n_img * Tn;
         const size_t xrow = (size_t)img * (Tn + 1);
         float* dst = x + xrow * a.D;
-        if (!a.stats) {
-            for (int d = threadIdx.x; d < a.D; d += blockDim.x) dst[d] = a.cls[d] + a.pos[d];
-            return;
-        }
-        // fused-LayerNorm path: also the operand-typed copy and the per-16-column partial moments
-        T* xb = a.xb ? reinterpret_cast<T*>(a.xb) + xrow * a.D : nullptr;
-        const int np = a.D >> 4;
-        for (int p = threadIdx.x; p < np; p += blockDim.x) {
-            float v[16], s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                v[j] = a.cls[16 * p + j] + a.pos[16 * p + j];
-                s += v[j];
-                dst[16 * p + j] = v[j];
-                if (xb) xb[16 * p + j] = from_float<T>(v[j]);
-            }
-            const float mean = s * 0.0625f;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) q += (v[j] - mean) * (v[j] - mean);
-            a.stats[(xrow * np + p) * 2 + 0] = s;
-            a.stats[(xrow * np + p) * 2 + 1] = q;
-        }
+        for (int d = threadIdx.x; d < a.D; d += blockDim.x) dst[d] = a.cls[d] + a.pos[d];
         return;
     }
     const int img = row / Tn, t = row - img * Tn;

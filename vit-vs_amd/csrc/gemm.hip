@@ -126,8 +126,8 @@ template <typename T, int BM, int BN, int KG, class Epi>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
                                                           int ks_i0) {
-    // ks_i0 packs [31:24] K per split-K slice / 32, [23:20] slices, [19:16] tile map, [15:0] i0: one preloaded
-    // dword instead of gridDim (hidden kernel arguments the wave would have to fetch) and an integer division.
+    // ks_i0 packs [31:24] K per split-K slice / 32, [15:0] i0: one preloaded dword instead of gridDim (hidden kernel
+    // arguments the wave would have to fetch) and an integer division.
 #ifdef VITVS_PROBE
     unsigned long long ts[8];
     ts[0] = __builtin_readcyclecounter();
@@ -138,23 +138,8 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned pk = (unsigned)ks_i0;
-    const int kslice = (int)(pk >> 24) * 32, nz = (pk >> 20) & 15, map = (pk >> 16) & 15;
-    int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
-    if (map != 0) {
-        // XCD-aware tile map (1-D grid).  Workgroup id i runs on XCD i % 8, and every XCD has its own L2: the 8th of
-        // the tiles an XCD gets is made a compact block of the (column, row x slice) grid - 2^(map-1) column groups,
-        // rows within a group, columns within a row - so that an activation block (fresh from the previous launch,
-        // i.e. read from HBM) is fetched by 1-2 XCDs instead of all 8, at the price of more XCDs per weight block.
-        const int nx = N / BN, ny = (M + BM - 1) / BM, nyy = ny * nz, tiles = nx * nyy, per = (tiles + 7) >> 3;
-        const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-        if (lin >= tiles) return;
-        const int cw = nx >> (map - 1);
-        const int cg = lin / (nyy * cw), rem = lin - cg * nyy * cw;
-        const int yy = rem / cw;
-        tx = cg * cw + (rem - yy * cw);
-        tz = yy / ny;
-        ty = yy - tz * ny;
-    }
+    const int kslice = (int)(pk >> 24) * 32;
+    const int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
     epi.set_slice(tz);
     const int m0 = ty * BM, n0 = tx * BN;
     f32x4 acc[Tile::NT][Tile::MT];
@@ -247,31 +232,13 @@ struct EpiArgs {   // host image of the flat epilogue arguments
 template <typename T, int BN, int KG, class Epi, int BM = 64>
 static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs& e, hipStream_t stream, int splits) {
     using Tile = GemmTile<BM, BN, KG>;
-    static bool raised = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES) != hipSuccess)
-            return -1;
-        raised = true;
-    }
+    static std::atomic<unsigned long long> raised{0};   // > 64 KiB of dynamic LDS needs the opt-in attribute, per device
+    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi>), Tile::LDS_BYTES, raised)) return -1;
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
     const int kslice = K / splits;
     if (kslice % 32 != 0 || kslice / 32 > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff) return -2;
-    // tile map: 0 = plain 3-D grid; m >= 1 = XCD-aware 1-D grid with 2^(m-1) column groups (one-wave launches only)
-    int map = 0;
-    const long tiles = (long)grid.x * grid.y * grid.z;
-    if (tiles <= 256) {
-        static const int forced = getenv("VITVS_GEMM_MAP") ? atoi(getenv("VITVS_GEMM_MAP")) : -1;
-        // measured (tools/op_chain pairs, profiles/r01_notes.md): the map pays for the split-K layers, whose activation
-        // operand is large relative to their run time (fc1 -> fc2: -0.85 us, attention -> proj: -0.3 us), and costs
-        // 0.4-0.6 us on qkv / fc1, whose weight blocks would be fetched by 4 XCDs instead of 2
-        // end to end the plain grid wins (2106 vs 2093 updates/s), so the map stays an experiment switch
-        map = forced >= 0 ? forced : 0;
-        while (map > 1 && (grid.x % (1u << (map - 1))) != 0) --map;
-        if (map) grid = dim3((unsigned)(8 * ((tiles + 7) / 8)));
-    }
     launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1, M,
-           N, K, (int)(((unsigned)(kslice / 32) << 24) | ((unsigned)splits << 20) | ((unsigned)map << 16) | (unsigned)e.i0));
+           N, K, (int)(((unsigned)(kslice / 32) << 24) | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -279,14 +246,7 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
 static bool big_problem(int M, int N, int splits) {
     // >= 256 tiles: with 2 workgroups per CU that is one round on every CU or more (measured: 294 tiles -12 %, 176 tiles
     // +37 % against 64x64 tiles)
-    static const long min_tiles = getenv("VITVS_BIG_MIN_TILES") ? atol(getenv("VITVS_BIG_MIN_TILES")) : 256;   // experiment switch
-    return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= min_tiles;
-}
-
-// Many rows but a narrow layer (N = D: proj, fc2): 128x64 tiles, 48 KB of LDS, three workgroups per CU.
-static bool tall_problem(int M, int N, int splits) {
-    static const long min_tiles = getenv("VITVS_TALL_MIN") ? atol(getenv("VITVS_TALL_MIN")) : 0;   // experiment switch, 0 = off
-    return min_tiles > 0 && splits == 1 && (long)((M + 127) / 128) * (N / 64) >= min_tiles;
+    return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= 256;
 }
 
 template <typename T, class Epi>
@@ -294,18 +254,7 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiAr
                         int splits = 1, bool fixed64 = false) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
-    TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
-    static const char* const forced_bn = getenv("VITVS_TILE_BN");   // experiment switch (read once): force the column-tile width
-    static const bool forced_kg2 = getenv("VITVS_TILE_KG2") != nullptr;
-    if (forced_bn) {
-        const int bn = atoi(forced_bn);
-        if ((bn == 64 || bn == 96 || bn == 128) && N % bn == 0) {
-            pl.bn = bn;
-            const long wgs = (long)((M + 63) / 64) * (N / bn);
-            pl.kg = (wgs <= 256 && (K / bk) >= 4 && (K / bk) % 2 == 0) ? 2 : 1;
-            if (forced_kg2 && (K / bk) % 2 == 0) pl.kg = 2;
-        }
-    }
+    const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
         return launch_one<T, 128, 1, Epi>(A, W, M, N, K, epi, stream, splits);
@@ -324,7 +273,6 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
                           int splits = 1) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
-    if (tall_problem(M, N, splits)) return launch_one<T, 64, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, true);
     if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
     return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);

@@ -50,17 +50,11 @@ struct GemmTile {
     static constexpr int MT = WM / 16, NT = WN / 16;    // 16x16 MFMA tiles per wave
     static constexpr int ROWS = BM + BN;
     static constexpr int L = ROWS / 32;                 // LDS-DMA instructions per wave per k-tile
-    // ring stages per k-group.  (A 4-stage ring for the two-k-group tiles that fit the 160 KB of LDS
-    // was measured 0.7 % SLOWER end to end at one frame pair: profiles/r01_notes.md.)
     // ring stages per k-group.  One-wave launches (64-row tiles, one workgroup per CU) want tiles in flight: 4 stages, 3
     // with two k-groups (a 4-stage ring there measured slower).  The 128-row tiles serve many-row problems that run
     // several waves of workgroups: there occupancy wins — 2 stages = 64 KB (128x128) or 48 KB (128x64), i.e. 2-3
     // workgroups per CU, measured -24 ... -27 % on the 6274-row fc1 / qkv GEMMs against 4 stages (1 workgroup per CU).
-#ifdef VITVS_LDS_BUDGET   // experiment switch (tools/op_chain): 4 stages wherever the rings fit this many bytes
-    static constexpr int NST = (KG * 4 * ROWS * 128 <= VITVS_LDS_BUDGET) ? 4 : 3;
-#else
     static constexpr int NST = (BM >= 128) ? 2 : ((KG == 1) ? 4 : 3);
-#endif
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
     static constexpr int RING_BYTES = KG * GROUP_BYTES;

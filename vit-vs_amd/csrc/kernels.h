@@ -1,6 +1,7 @@
 // Internal launch interface between the C-ABI layer (api.cpp) and the HIP kernels.
 // All pointers are device pointers; every launch is asynchronous on `stream`.
 #pragma once
+#include <atomic>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -35,6 +36,23 @@ inline void launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stre
     }
 }
 
+// The HIP device the calling thread's current entry point runs on (set by the C-ABI layer's DeviceScope; api.hip).
+extern thread_local int g_current_device;
+inline int current_device() {
+    if (g_current_device < 0) (void)hipGetDevice(&g_current_device);
+    return g_current_device;
+}
+// Kernels that need more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, and the attribute is kept per
+// (function, DEVICE): `done` holds one bit per device for one kernel instantiation.
+inline int raise_lds_limit(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64) return -1;
+    if ((done.load(std::memory_order_relaxed) >> dev) & 1ull) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    return 0;
+}
+
 enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };   // operand type of the GEMMs / attention; fp32 accumulate
 
 inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
@@ -55,17 +73,6 @@ int launch_linear_partial(Precision p, const void* A, const void* W, float* part
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
                        int n_img, int T, int D, int Kp, hipStream_t stream);
 
-// ---- gemm_fused.hip: linear layers with the LayerNorm folded in (see the file header) ---------------
-// out = act(LayerNorm(x) W^T + bias) computed as rstd*(A Wf^T) - rstd*mu*c1 + c2 with A = raw residual stream
-// (operand type), Wf = gamma-folded weight, row moments merged from `stats` ([M][D/16][2]); K must equal D.
-int launch_linear_ln(Precision p, const void* A, const void* Wf, const float* c1, const float* c2, const float* stats,
-                     int D, void* out, int M, int N, int K, int gelu, float eps, hipStream_t stream);
-// x += ls * (A W^T + bias); also writes xb (operand-typed copy, bf16 mode) and the partial moments of the new rows.
-int launch_linear_residual_stats(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
-                                 void* xb, float* stats, int M, int N, int K, hipStream_t stream);
-int launch_patch_embed_stats(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
-                             void* xb, float* stats, int n_img, int T, int D, int Kp, hipStream_t stream);
-
 // ---- elementwise.hip -----------------------------------------------------------------------
 struct PatchifyArgs {
     const uint8_t* des;   // [n_des][S][S][3] RGB u8
@@ -75,8 +82,6 @@ struct PatchifyArgs {
     float mean[3], std[3];
     const float* cls;     // [D]
     const float* pos;     // [1+T][D]
-    void* xb;             // fused-LayerNorm path: operand-typed copy of x (null in fp32 mode / legacy path)
-    float* stats;         // fused-LayerNorm path: [rows][D/16][2] partial moments (null = legacy path)
 };
 // Ape[(img*T + t)][k] = ((u8/255) - mean_c)/std_c for k = c*p*p + py*p + px (zero for k >= 3p²);
 // x[img*(T+1)][:] = cls + pos[0].

@@ -412,13 +412,8 @@ int launch_servo(const ServoArgs& a, hipStream_t stream) {
     if (a.mode == SEL_DENSE && a.max_rows < a.T) return -2;
     const size_t lds = servo_f64_offset(a.T, a.max_rows) + (size_t)7 * kLdsRows * 8 + (40 + 8 * 27) * 8;
     if (lds > 160 * 1024) return -3;
-    static bool raised = false;   // > 64 KiB of dynamic LDS (dense selection over thousands of tokens) needs the opt-in
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&servo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return -3;
-        raised = true;
-    }
+    static std::atomic<unsigned long long> raised{0};   // > 64 KiB of dynamic LDS (dense selection over thousands of tokens): per-device opt-in
+    if (lds > 64 * 1024 && raise_lds_limit(reinterpret_cast<const void*>(&servo_kernel), 160 * 1024, raised)) return -3;
     launch(servo_kernel, dim3(a.n_pairs), dim3(256), lds, stream, a.row_best, a.col_best, a.K, a.selection, a.depth, a.T,
            a.mode, a.sel_stride, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;

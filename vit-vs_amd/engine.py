@@ -44,7 +44,9 @@ class Engine:
         self.binned = self.params.use_feature_binning if binned is None else bool(binned)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_pairs = int(max_pairs)
-        self.max_rows = int(max_rows) if max_rows is not None else int(self.params.num_pairs)
+        # capacity in feature pairs per frame pair: the reference's rotation search raises num_pairs to 48 for its calls
+        # (vitvs_v2.py:1151-1189), so that is the default floor
+        self.max_rows = int(max_rows) if max_rows is not None else max(int(self.params.num_pairs), 48)
         c = _lib.VitvsConfig()
         c.abi_version = _lib.ABI_VERSION
         c.img_size, c.patch, c.stride, c.dim = cfg.img_size, cfg.patch, cfg.stride, cfg.dim
@@ -182,13 +184,19 @@ class Engine:
         self._check(rc, "vitvs_correspond_dev")
         return (nn1, nn2, sim1, smat) if want_matrix else (nn1, nn2, sim1)
 
-    def _selection_args(self, mode, selection, n_pairs, tokens):
+    def _num_pairs(self, num_pairs) -> int:
+        k = int(self.params.num_pairs if num_pairs is None else num_pairs)
+        if not 1 <= k <= self.max_rows:
+            raise VitvsError(f"num_pairs {k} outside 1..max_rows ({self.max_rows})")
+        return k
+
+    def _selection_args(self, mode, selection, n_pairs, tokens, num_pairs=None):
         if mode == _lib.SELECT_DENSE:
             return None, None
         if selection is None:
             raise VitvsError("this selection mode needs a selection array")
         if mode == _lib.SELECT_EXPLICIT:
-            k = self.params.num_pairs
+            k = self._num_pairs(num_pairs)
             sel = torch.full((n_pairs, k), 0, dtype=torch.int32)
             cnt = torch.zeros(n_pairs, dtype=torch.int32)
             rows = selection if isinstance(selection, (list, tuple)) else [selection]
@@ -202,8 +210,8 @@ class Engine:
         order = torch.as_tensor(selection, dtype=torch.int32).reshape(n_pairs, tokens)
         return order.to(self.device).contiguous(), None
 
-    def servo_from_nn(self, nn_1, nn_2, sim_1, depth, K, mode=_lib.SELECT_DENSE, selection=None):
-        """Control law on given nearest-neighbour tables (one pair)."""
+    def servo_from_nn(self, nn_1, nn_2, sim_1, depth, K, mode=_lib.SELECT_DENSE, selection=None, num_pairs=None):
+        """Control law on given nearest-neighbour tables (one pair); ``num_pairs`` as in ``compute_velocity``."""
         nn1 = torch.as_tensor(nn_1).to(self.device, torch.int32).contiguous()
         nn2 = torch.as_tensor(nn_2).to(self.device, torch.int32).contiguous()
         s1 = torch.as_tensor(sim_1).to(self.device, torch.float32).contiguous()
@@ -212,12 +220,13 @@ class Engine:
         if z is not None and (z.dtype != torch.uint16 or tuple(z.shape[-2:]) != (self.params.v_max, self.params.u_max)):
             raise VitvsError("depth must be uint16 [v_max,u_max]")
         kk = torch.as_tensor(K, dtype=torch.float64).reshape(1, 4).to(self.device)
-        sel, cnt = self._selection_args(mode, selection, 1, t)
+        k = self._num_pairs(num_pairs)
+        sel, cnt = self._selection_args(mode, selection, 1, t, k)
         v = torch.zeros((1, 6), dtype=torch.float64, device=self.device)
         st = torch.zeros(1, dtype=torch.int32, device=self.device)
         n_sel = int(cnt[0].item()) if cnt is not None else 0
         rc = self.lib.vitvs_servo_from_nn_dev(self.handle, t, _ptr(nn1), _ptr(nn2), _ptr(s1), _ptr(z), _ptr(kk), mode,
-                                              _ptr(sel), n_sel, _ptr(v), _ptr(st), _stream_ptr(self.device))
+                                              _ptr(sel), n_sel, k, _ptr(v), _ptr(st), _stream_ptr(self.device))
         self._check(rc, "vitvs_servo_from_nn_dev")
         self._last_tokens = t
         return v[0], st[0]
@@ -226,22 +235,25 @@ class Engine:
     def compute_velocity_dev(self, I_cur: torch.Tensor, I_des: torch.Tensor, Z: Optional[torch.Tensor],
                              K: torch.Tensor, mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
                              n_selected: Optional[torch.Tensor] = None, des_shared: bool = False,
-                             out_v: Optional[torch.Tensor] = None, out_status: Optional[torch.Tensor] = None):
+                             out_v: Optional[torch.Tensor] = None, out_status: Optional[torch.Tensor] = None,
+                             num_pairs: int = 0):
         """Device-resident call: every argument is a CUDA tensor already laid out as the C ABI
-        wants it; work is enqueued on the current stream and nothing synchronises."""
+        wants it; work is enqueued on the current stream and nothing synchronises.  ``num_pairs`` = feature pairs of the
+        law for this call (0: the engine's default)."""
         n = I_cur.shape[0]
         v = out_v if out_v is not None else torch.empty((n, 6), dtype=torch.float64, device=self.device)
         st = out_status if out_status is not None else torch.empty(n, dtype=torch.int32, device=self.device)
         rc = self.lib.vitvs_compute_velocity_dev(self.handle, n, _ptr(I_cur), _ptr(I_des), int(des_shared), _ptr(Z),
-                                                 _ptr(K), mode, _ptr(selection), _ptr(n_selected), _ptr(v), _ptr(st),
-                                                 _stream_ptr(self.device))
+                                                 _ptr(K), mode, _ptr(selection), _ptr(n_selected), int(num_pairs), _ptr(v),
+                                                 _ptr(st), _stream_ptr(self.device))
         self._check(rc, "vitvs_compute_velocity_dev")
         self._last_tokens = self.tokens
         return v, st
 
     def compute_velocity(self, I_cur, I_des, Z, K, mode: int = _lib.SELECT_DENSE, selection=None,
-                         des_shared: bool = False):
-        """Convenience form: numpy / CPU inputs are moved to the device, then the device path runs."""
+                         des_shared: bool = False, num_pairs: Optional[int] = None):
+        """Convenience form: numpy / CPU inputs are moved to the device, then the device path runs.  ``num_pairs``:
+        the reference's ``Controller.num_pairs`` for this call (default: the engine's parameters)."""
         cur = self._frames(I_cur)
         des = self._frames(I_des)
         n = cur.shape[0]
@@ -257,8 +269,9 @@ class Engine:
         if kk.shape[0] == 1 and n > 1:
             kk = kk.expand(n, 4)
         kk = kk.contiguous().to(self.device)
-        sel, cnt = self._selection_args(mode, selection, n, self.tokens)
-        return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared)
+        k = self._num_pairs(num_pairs)
+        sel, cnt = self._selection_args(mode, selection, n, self.tokens, k)
+        return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared, num_pairs=k)
 
     # ------------------------------------------------------------------ measurement hooks
     def timing_enable(self, on: bool = True):

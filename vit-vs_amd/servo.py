@@ -8,6 +8,7 @@ Same names, argument meaning and error behaviour as the reference's callables, w
   Controller.detect_features() / .ibvs()      reference: vitvs_v2.py:464-523, 588-632 (EMA :325-343, failure
                                               counter :500-505, twist remap :661-676)
   Controller.best_rotation(frames)            reference: find_and_set_best_pose, vitvs_v2.py:1151-1189
+  ServoLoop (vit-vs_amd/loop.py)              reference: Controller.run / is_visual_servoing_done, :702-819, :345-421
 
 All arithmetic of the path runs on the GPU through ``Engine`` (C ABI); what stays on the host is what the
 reference also does on the host: PIL resize, the RNG draw, the EMA state and the twist remap.
@@ -28,7 +29,7 @@ STATUS_NAMES = {0: "ok", 1: "no_correspondence", 2: "too_few_features", 3: "no_d
 
 # ------------------------------------------------------------------------------------------ functional API
 def compute_velocity(engine: Engine, I_cur, I_des, Z, K=None, *, selection="order",
-                     generator: Optional[torch.Generator] = None):
+                     generator: Optional[torch.Generator] = None, num_pairs: Optional[int] = None):
     """One servo update for one frame pair: raw (pre-EMA) ``v_c`` float64[6] and a status int.
 
     ``I_cur`` / ``I_des``: uint8 RGB frames already at the extractor's input size (the reference resizes with
@@ -40,15 +41,17 @@ def compute_velocity(engine: Engine, I_cur, I_des, Z, K=None, *, selection="orde
                    correspondence and the control law; two device round trips, as in the reference)
       "dense"      every mutual-NN token
       array-like   explicit token ids of the desired frame
+    ``num_pairs``: feature pairs of the law for this call (the reference's ``Controller.num_pairs``; default: the
+    engine's parameters).
     """
     one = lambda a: a[None] if torch.is_tensor(a) else np.asarray(a)[None]   # noqa: E731  (device tensors stay there)
     v, st = compute_velocity_batch(engine, one(I_cur), one(I_des), None if Z is None else one(Z), K, selection=selection,
-                                   generator=generator)
+                                   generator=generator, num_pairs=num_pairs)
     return v[0], int(st[0])
 
 
 def compute_velocity_batch(engine: Engine, I_cur, I_des, Z, K=None, *, selection="order", des_shared: bool = False,
-                           generator: Optional[torch.Generator] = None):
+                           generator: Optional[torch.Generator] = None, num_pairs: Optional[int] = None):
     """``B`` pairs in one call → (v_c float64 [B,6], status int32 [B]) as numpy arrays."""
     p = engine.params
     K = p.intrinsics() if K is None else K
@@ -56,17 +59,17 @@ def compute_velocity_batch(engine: Engine, I_cur, I_des, Z, K=None, *, selection
     if isinstance(selection, str) and selection == "reference":
         if n != 1:
             raise ValueError('selection="reference" follows the reference: one pair per call')
-        return _reference_update(engine, I_cur, I_des, Z, K, generator)
+        return _reference_update(engine, I_cur, I_des, Z, K, generator, num_pairs)
     if isinstance(selection, str) and selection == "order":
         order = torch.stack([torch.randperm(engine.tokens, generator=generator) for _ in range(n)]).to(torch.int32)
         v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_ORDER, selection=order,
-                                        des_shared=des_shared)
+                                        des_shared=des_shared, num_pairs=num_pairs)
     elif isinstance(selection, str) and selection == "dense":
         v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_DENSE, des_shared=des_shared)
     else:
         ids = selection if isinstance(selection, (list, tuple)) and n > 1 else [selection]
         v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_EXPLICIT, selection=list(ids),
-                                        des_shared=des_shared)
+                                        des_shared=des_shared, num_pairs=num_pairs)
     return v.cpu().numpy(), st.cpu().numpy()
 
 
@@ -108,23 +111,42 @@ def find_correspondences_batch(engine: Engine, descriptors1: torch.Tensor, descr
     return rc(chosen), rc(nn_1[chosen]), sim_1[chosen].unsqueeze(0)
 
 
-def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator):
-    frames = np.concatenate([np.asarray(I_des), np.asarray(I_cur)])
-    desc = engine.extract_descriptors(frames)
+def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator, num_pairs=None):
+    """The reference's own sequence with ONE forward: descriptors of both frames, similarity + arg-max on the device,
+    the reference's sort + ``randperm`` draw on the host (same torch RNG stream), then the control law on the device
+    for the drawn tokens.  Frames may be numpy arrays or device tensors (``Controller._resized`` returns the latter)."""
+    k = engine.params.num_pairs if num_pairs is None else int(num_pairs)
+    both = torch.cat([torch.as_tensor(I_des).to(engine.device), torch.as_tensor(I_cur).to(engine.device)])
+    desc = engine.extract_descriptors(both)
+    d1, d2 = desc[0, 0], desc[1, 0]
+    nn_1, nn_2, sim_1 = engine.correspond(d1, d2)
     if generator is not None:
         state = torch.get_rng_state()
         torch.set_rng_state(generator.get_state())
     try:
-        p1, _, _ = find_correspondences_batch(engine, desc[0:1], desc[1:2], num_pairs=engine.params.num_pairs)
+        ids = _draw_like_the_reference(nn_1.cpu().long(), nn_2.cpu().long(), sim_1.cpu(), engine.cfg.grid, k)
     finally:
         if generator is not None:
             generator.set_state(torch.get_rng_state())
             torch.set_rng_state(state)
-    if p1 is None:
+    z = None if Z is None else torch.as_tensor(Z).reshape(engine.params.v_max, engine.params.u_max)
+    if ids is None:                                       # (None, None, None) in the reference
         return np.zeros((1, 6)), np.array([_lib.STATUS_NO_CORRESPONDENCE], np.int32)
-    ids = (p1[:, 0] * engine.cfg.grid + p1[:, 1]).to(torch.int32)
-    v, st = engine.compute_velocity(I_cur, I_des, Z, K, mode=_lib.SELECT_EXPLICIT, selection=[ids])
-    return v.cpu().numpy(), st.cpu().numpy()
+    v, st = engine.servo_from_nn(nn_1, nn_2, sim_1, z, K, mode=_lib.SELECT_EXPLICIT, selection=[ids.to(torch.int32)],
+                                 num_pairs=k)
+    return v.cpu().numpy()[None], np.array([int(st)], np.int32)
+
+
+def _draw_like_the_reference(nn_1, nn_2, sim_1, grid: int, num_pairs: int):
+    """Token ids of the desired frame as ``find_correspondences_batch`` draws them (vitvs_v2.py:84-141), or None."""
+    t = nn_1.numel()
+    if sim_1.mean().item() > 0.99:                       # same-image shortcut
+        return torch.randperm(t)[:min(num_pairs, t)]
+    cand = _candidate_order(nn_1, nn_2, grid)
+    k = min(num_pairs, cand.numel())
+    if k == 0:
+        return None
+    return cand[torch.randperm(cand.numel())[:k]]
 
 
 def ema_update(state: list, v: Sequence[float], alpha: float) -> np.ndarray:
@@ -160,8 +182,9 @@ class Controller:
         self.selection = selection
         self.feature_failure_count = 0
         self.ema_velocities = [None] * 6
-        self.v_c = np.zeros(6)
+        self.v_c = None                                   # like the reference (vitvs_v2.py:224): unset until the first update
         self.velocity_vector_history = []
+        self.max_velocity_vector_history = 200            # config.yaml:37
         self.last_status = None
 
     # -- inputs (the reference's ROS callbacks)
@@ -194,7 +217,8 @@ class Controller:
         depth = self.latest_image_depth
         # the law needs a depth image; detect_features itself does not, so feed a dummy one if it is missing
         z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
-        v, st = compute_velocity(self.engine, cur, des, z, self.params.intrinsics(), selection=self.selection)
+        v, st = compute_velocity(self.engine, cur, des, z, self.params.intrinsics(), selection=self.selection,
+                                 num_pairs=self.num_pairs)
         self._raw_v, self.last_status = v, st
         if st == _lib.STATUS_NO_CORRESPONDENCE:
             self.feature_failure_count += 1
@@ -219,30 +243,49 @@ class Controller:
             return
         if self.latest_image_depth is None:               # reference: "Failed to get depth - skipping"
             return
+        # fewer than 4 matches: the reference's calculate_uv hands back all-zero feature arrays of num_pairs rows
+        # (vitvs_v2.py:539-541), len() >= 4 passes the check at :604, e = 0 and the raw twist is exactly 0 — which is
+        # what the kernel reports with status TOO_FEW; the EMA is updated with it, as in the reference
         self.v_c = ema_update(self.ema_velocities, self._raw_v, self.params.ema_alpha)
         self.velocity_vector_history.append(self.v_c)
+        if len(self.velocity_vector_history) > self.max_velocity_vector_history:
+            self.velocity_vector_history.pop(0)
 
     def publish_twist(self, v_c=None):
         return twist_from_velocity(self.v_c if v_c is None else v_c, self.params.max_velocity)
 
     # -- rotation compensation: 4 (or any number of) candidate views against the one goal image
-    def best_rotation(self, candidate_frames: Sequence):
-        """Index of the candidate current frame whose selected correspondences are most similar on average
-        (reference: score = sim_selected_12.mean(), with num_pairs = 48 there — build the engine with the
-        num_pairs you want scored), evaluated as ONE batch sharing the goal forward."""
+    ROTATION_SEARCH_PAIRS = 48                            # vitvs_v2.py:1158
+
+    def best_rotation(self, candidate_frames: Sequence, generator: Optional[torch.Generator] = None):
+        """Index of the candidate current frame whose selected correspondences are most similar on average, and the
+        scores (reference: find_and_set_best_pose — ``num_pairs`` raised to 48 for these calls, score =
+        ``sim_selected_12.mean()``, the first best wins, failed views are skipped), evaluated as ONE batch of
+        ``len(candidate_frames)`` pairs sharing the goal forward.  Returns ``(None, scores)`` if every view failed."""
         eng = self.engine
-        if eng.max_pairs < len(candidate_frames):
+        n = len(candidate_frames)
+        if eng.max_pairs < n:
             raise ValueError("engine.max_pairs is smaller than the number of candidates")
+        k = self.ROTATION_SEARCH_PAIRS
+        if eng.max_rows < k:
+            raise ValueError(f"engine.max_rows must be >= {k} for the rotation search")
         dev = eng.device
         cur = torch.stack([torch.as_tensor(self._resized(f)).to(dev) for f in candidate_frames])
         des = torch.as_tensor(self._resized(self.goal_image)).to(dev)[None]
-        z = np.zeros((len(cur), self.params.v_max, self.params.u_max), np.uint16)
-        order = torch.stack([torch.randperm(eng.tokens) for _ in range(len(cur))]).to(torch.int32)
-        eng.compute_velocity(cur, des, z, self.params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
-                             des_shared=True)
-        det = eng.last_details(len(cur))
-        scores = []
-        for b in range(len(cur)):
-            n = int(det["info"][b, 3])
-            scores.append(float(det["feat"][b, :n, 3].mean()) if n > 0 else -np.inf)
-        return int(np.argmax(scores)), scores
+        z = np.zeros((n, self.params.v_max, self.params.u_max), np.uint16)
+        order = torch.stack([torch.randperm(eng.tokens, generator=generator) for _ in range(n)]).to(torch.int32)
+        _, st = eng.compute_velocity(cur, des, z, self.params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
+                                     des_shared=True, num_pairs=k)
+        det = eng.last_details(n)
+        status = st.cpu().numpy()
+        scores, best, best_mean = [], None, float("-inf")
+        for b in range(n):
+            m = int(det["info"][b, 3])
+            if status[b] == _lib.STATUS_NO_CORRESPONDENCE or m == 0:
+                scores.append(None)                       # "Feature detection failed for this rotation"
+                continue
+            mean = float(det["feat"][b, :m, 3].astype(np.float32).mean())
+            scores.append(mean)
+            if mean > best_mean:
+                best_mean, best = mean, b
+        return best, scores

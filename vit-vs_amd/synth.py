@@ -108,3 +108,7 @@ ACCEPTED_FRAME_SEEDS = {
     "vitb8_448": 20250705,
     "vitl14_518": 20250705,
 }
+
+# BASELINE.json configs[3] (8-camera rig: 8 ViT-B/16 224² pairs, one per GPU): the first 8 frame seeds from the headline
+# seed upward that meet the same acceptance rule (tests/golden/rig8_vitb16_224.npz, oracle/make_golden.py rig8).
+RIG8_FRAME_SEEDS = (20250715, 20250716, 20250717, 20250726, 20250727, 20250728, 20250730, 20250737)
