@@ -113,7 +113,8 @@ def _attention_ref(qkv, n_img, N, H):
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("n_img,N,H,scale", [(2, 197, 6, 1.0), (1, 64, 2, 1.0), (1, 70, 1, 3.0), (2, 257, 2, 2.0),
-                                             (1, 1370, 2, 1.0), (3, 5, 1, 1.0)])
+                                             (1, 1370, 2, 1.0), (3, 5, 1, 1.0), (2, 530, 3, 2.0), (1, 700, 1, 4.0),
+                                             (1, 3137, 1, 1.0), (9, 197, 12, 1.0)])
 def test_attention(lib, name, prec, dtype, tol, n_img, N, H, scale):
     g = torch.Generator().manual_seed(N * 3 + H)
     D = H * 64
@@ -180,3 +181,64 @@ def test_split_k_pair(lib, name, prec, dtype, tol, M, D, K, use_ls, use_ln):
     assert _rel(x.cpu(), x_ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)      # fp32 accumulate, fp32 residual stream
     if use_ln:
         assert _rel(out.cpu(), y_ref) <= {_lib.F32: 2e-5, _lib.BF16: 1e-2, _lib.F16: 2e-3}[prec]
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
+@pytest.mark.parametrize("variant", [256, 128, 1])
+@pytest.mark.parametrize("M,N,K,gelu", [(6274, 2304, 768, 0), (2740, 1024, 1024, 1), (1025, 256, 128, 0), (3152, 768, 3072, 1),
+                                        (300, 512, 192, 0)])
+def test_linear_tile_families_agree_with_the_reference(lib, name, prec, dtype, tol, variant, M, N, K, gelu):
+    """The 256-row tiles of gemm_big.hip (both column widths) and the tiles of gemm.hip on the same shapes: ragged last
+    row tile (M % 256 != 0), the shortest k-loop the big kernel accepts (K = 128: prologue + two tail k-tiles only), odd
+    and even k-tile counts, and a row count below one tile."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((N, K), g, K ** -0.5).to(dtype)
+    bias = _mk((N,), g, 0.1)
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    out = torch.full((M + 3, N), float("nan"), dtype=dtype, device="cuda")      # 3 guard rows behind the matrix
+    rc = lib.vitvs_op_linear_variant(prec, variant, _p(Ad), _p(Wd), _p(bd), _p(out), M, N, K, gelu, 0, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all(), "rows beyond M were written"
+    assert torch.isfinite(out[:M].float()).all()
+    assert _rel(out[:M].cpu(), ref) <= tol
+
+
+@pytest.mark.parametrize("variant", [256, 128, 1])
+@pytest.mark.parametrize("M,N,K,slices", [(6274, 768, 3072, 3), (2740, 1024, 1024, 2), (1500, 256, 768, 1)])
+def test_linear_partial_tile_families(lib, variant, M, N, K, slices):
+    """Split-K partial sums from both tile families: slice z holds exactly the products of its K range (fp32)."""
+    g = torch.Generator().manual_seed(M + N + K + slices)
+    A = _mk((M, K), g).to(torch.bfloat16)
+    W = _mk((N, K), g, K ** -0.5).to(torch.bfloat16)
+    Ad, Wd = A.cuda(), W.cuda()
+    part = torch.full((slices, M, N), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.vitvs_op_linear_variant(_lib.BF16, variant, _p(Ad), _p(Wd), None, _p(part), M, N, K, 0, slices, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ks = K // slices
+    for z in range(slices):
+        ref = A[:, z * ks:(z + 1) * ks].double() @ W[:, z * ks:(z + 1) * ks].double().t()
+        assert _rel(part[z].cpu(), ref) <= 2e-6 + 1e-3
+
+
+def test_long_attention_rescale_branch_is_forced(lib):
+    """Online softmax of the 128-query kernel (N >= 512): the running maximum of chosen queries jumps at chosen key tiles
+    (a key that matches them far better than every earlier one), so the exact-rescale branch is taken late in the key
+    loop, with and without a ragged last tile; full-tensor fp64 reference."""
+    for N in (640, 777):
+        g = torch.Generator().manual_seed(N)
+        qkv = _mk((N, 192), g, 0.5)
+        for qrow, krow in ((3, 70), (130, 400), (131, 639), (600, N - 1), (17, 5)):
+            qkv[krow, 64:128] = qkv[qrow, 0:64] * 6.0          # key `krow` aligned with query `qrow`: a late, large maximum
+        for prec, dtype, tol in ((_lib.BF16, torch.bfloat16, 2e-2), (_lib.F16, torch.float16, 3e-3)):
+            q = qkv.to(dtype)
+            out = torch.full((N, 64), float("nan"), dtype=dtype, device="cuda")
+            qd = q.cuda()
+            assert lib.vitvs_op_attention(prec, _p(qd), _p(out), 1, N, 1, _stream()) == 0
+            torch.cuda.synchronize()
+            assert _rel(out.cpu(), _attention_ref(q, 1, N, 1)) <= tol

@@ -534,7 +534,7 @@ def test_two_handles_interleaved():
     pa = config.ServoParams(dino_input_size=ca.img_size, use_feature_binning=False)
     pb = config.ServoParams(dino_input_size=cb.img_size, use_feature_binning=False)
     ea = _engine(ca, pa, precision="bf16", max_pairs=2).load_state_dict(weights.synthetic_state_dict(ca, 0))
-    eb = _engine(cb, pb, precision="fp32", max_pairs=1, max_rows=cb.tokens).load_state_dict(weights.synthetic_state_dict(cb, 4))
+    eb = _engine(cb, pb, precision="fp32", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cb, 4))
     fa = np.stack(synth.frame_pair(ca.img_size, 31))
     fb = np.stack(synth.frame_pair(cb.img_size, 32))
     ta0, tb0 = ea.forward_tokens(fa).cpu(), eb.forward_tokens(fb).cpu()

@@ -1,0 +1,115 @@
+// Many-row operators on RANDOM data (zero-filled operands read 15-20 % high on this chip: the clock it holds depends on
+// the data): each linear layer of the many-row configurations on every tile family, and the long-sequence attention.
+// Build: make -C tools      Run: HIP_FORCE_DEV_KERNARG=1 tools/big_ops [fast]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+#include <vector>
+
+#include "vitvs.h"
+#include "vitvs_ops.h"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+static void* rand_bf16(size_t n, float scale, unsigned seed) {
+    std::vector<unsigned short> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const float u = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;      // uniform [-1, 1)
+        h[i] = bf16_of(u * scale);
+    }
+    void* p;
+    CHECK(hipMalloc(&p, n * 2));
+    CHECK(hipMemcpy(p, h.data(), n * 2, hipMemcpyHostToDevice));
+    return p;
+}
+
+static double run(hipStream_t st, int reps, const std::function<int()>& op) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) if (op()) return -1.0;
+    CHECK(hipStreamSynchronize(st));
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) op();
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    return best * 1e3 / reps;   // us
+}
+
+int main(int argc, char** argv) {
+    const bool fast = argc > 1 && !strcmp(argv[1], "fast");
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    struct Shape { const char* name; int M, N, K, gelu, slices; };
+    const Shape shapes[] = {
+        {"ViT-B/8 448  qkv ", 6274, 2304, 768, 0, 0},  {"ViT-B/8 448  fc1 ", 6274, 3072, 768, 1, 0},
+        {"ViT-B/8 448  fc2 ", 6274, 768, 3072, 0, 1},  {"ViT-B/8 448  proj", 6274, 768, 768, 0, 1},
+        {"8 x ViT-B/16 qkv ", 3152, 2304, 768, 0, 0},  {"8 x ViT-B/16 fc1 ", 3152, 3072, 768, 1, 0},
+        {"8 x ViT-B/16 fc2 ", 3152, 768, 3072, 0, 1},  {"8 x ViT-B/16 proj", 3152, 768, 768, 0, 1},
+        {"ViT-L/14 518 qkv ", 2740, 3072, 1024, 0, 0}, {"ViT-L/14 518 fc1 ", 2740, 4096, 1024, 1, 0},
+        {"ViT-L/14 518 fc2 ", 2740, 1024, 4096, 0, 1}, {"ViT-L/14 518 proj", 2740, 1024, 1024, 0, 1},
+        {"4 x ViT-B/16 fc1 ", 1576, 3072, 768, 1, 0},  {"2 x ViT-B/16 fc1 ", 788, 3072, 768, 1, 0},
+    };
+    const bool sweep = argc > 1 && !strcmp(argv[1], "sweep");
+    // K sweep at fixed M x N: separates the per-k-tile time from the fixed cost of a tile (prologue, epilogue, launch)
+    const Shape sweep_shapes[] = {
+        {"6274x2304 K=128  ", 6274, 2304, 128, 0, 0},  {"6274x2304 K=256  ", 6274, 2304, 256, 0, 0},
+        {"6274x2304 K=512  ", 6274, 2304, 512, 0, 0},  {"6274x2304 K=768  ", 6274, 2304, 768, 0, 0},
+        {"6274x2304 K=1536 ", 6274, 2304, 1536, 0, 0}, {"6274x2304 K=3072 ", 6274, 2304, 3072, 0, 0},
+        {"1500x2304 K=128  ", 1500, 2304, 128, 0, 0},  {"1500x2304 K=768  ", 1500, 2304, 768, 0, 0},
+        {"1500x2304 K=3072 ", 1500, 2304, 3072, 0, 0},
+    };
+    const int nsets = 4;
+    printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, classic, 256x256, 256x128");
+    std::vector<Shape> todo;
+    if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
+    else todo.assign(std::begin(shapes), std::end(shapes));
+    for (const Shape& s : todo) {
+        void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
+        void* Wt[nsets];
+        for (int i = 0; i < nsets; ++i) Wt[i] = rand_bf16((size_t)s.N * s.K, 0.05f, 2 + i);
+        void* out;
+        const int sl = s.slices;
+        CHECK(hipMalloc(&out, (size_t)(sl ? sl * 4 : 2) * s.M * s.N + 256));
+        float* bias;
+        CHECK(hipMalloc((void**)&bias, s.N * 4));
+        CHECK(hipMemset(bias, 0, s.N * 4));
+        const double flop = 2.0 * s.M * s.N * s.K;
+        printf("%-20s %6d %6d %6d |", s.name, s.M, s.N, s.K);
+        for (int variant : {0, 1, 256, 128}) {
+            int turn = 0;
+            const double us = run(st, fast ? 20 : 60, [&] {
+                return vitvs_op_linear_variant(VITVS_BF16, variant, A, Wt[(turn++) % nsets], bias, out, s.M, s.N, s.K, s.gelu, sl, st);
+            });
+            if (us < 0) printf("     n/a      ");
+            else printf(" %7.1f %6.0f", us, flop / us * 1e-6);
+        }
+        printf("\n");
+        fflush(stdout);
+        CHECK(hipFree(A)); CHECK(hipFree(out)); CHECK(hipFree(bias));
+        for (int i = 0; i < nsets; ++i) CHECK(hipFree(Wt[i]));
+    }
+    if (sweep) return 0;
+    // long-sequence attention: (images, tokens, heads)
+    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}};
+    for (auto& a : att) {
+        const int n_img = a[0], N = a[1], H = a[2], D = H * 64;
+        void* qkv = rand_bf16((size_t)n_img * N * 3 * D, 1.0f, 9);
+        void* out;
+        CHECK(hipMalloc(&out, (size_t)n_img * N * D * 2));
+        const double us = run(st, fast ? 10 : 30, [&] { return vitvs_op_attention(VITVS_BF16, qkv, out, n_img, N, H, st); });
+        printf("attention %d x %d tokens x %d heads: %8.1f us  %6.0f TFLOP/s\n", n_img, N, H, us, 4.0 * n_img * N * (double)N * D / us * 1e-6);
+        CHECK(hipFree(qkv)); CHECK(hipFree(out));
+    }
+    return 0;
+}

@@ -849,6 +849,20 @@ int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float
     DeviceScope dev(nullptr);
     return launch_linear(to_prec(precision), A, W, bias, out, M, N, K, gelu, as_stream(stream));
 }
+int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, const void* W, const float* bias, void* out,
+                            int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t slices, void* stream) {
+    DeviceScope dev(nullptr);
+    const Precision p = to_prec(precision);
+    hipStream_t st = as_stream(stream);
+    if (variant == 0)
+        return slices > 0 ? launch_linear_partial(p, A, W, (float*)out, M, N, K, slices, st)
+                          : launch_linear(p, A, W, bias, out, M, N, K, gelu, st);
+    if (variant == 1)
+        return slices > 0 ? launch_linear_partial_classic(p, A, W, (float*)out, M, N, K, slices, st)
+                          : launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, st);
+    if ((variant != 256 && variant != 128) || N % variant != 0 || K % 64 != 0) return -2;
+    return launch_linear_big(p, variant, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
+}
 int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
                              float* x, int32_t M, int32_t N, int32_t K, void* stream) {
     DeviceScope dev(nullptr);

@@ -29,6 +29,7 @@ namespace vitvs {
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * log2(e), hd = 64
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
+__device__ __forceinline__ void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------ bf16
 template <typename HT, int KS>
@@ -193,6 +194,202 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
         for (int td = 0; td < 4; ++td) {
             const hx4 o = {(HT)(acc_o[td][0] * inv), (HT)(acc_o[td][1] * inv), (HT)(acc_o[td][2] * inv), (HT)(acc_o[td][3] * inv)};
             store_out<(KS >= 2)>(dst + 16 * td, o);   // key-split variants only run on small grids
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ 16-bit, long sequences
+// N >= 512 (448² / 518² inputs: 3137 / 1370 tokens).  The 64-query kernel above is bound by the K / V traffic into LDS
+// (every 64 queries re-read the (image, head)'s whole K and V: 0.94 GB per launch at 3137 tokens) and by exposed LDS
+// latency (each MFMA waits for the fragment read issued just before it).  Here:
+//   * one workgroup = 128 queries, wave w = queries 32 w .. 32 w + 31 as two 16-query tiles that share every K and V
+//     fragment read (half the LDS traffic per MFMA, half the K / V traffic per query);
+//   * K / V tiles of 64 keys arrive by LDS-DMA into a 3-stage ring with counted waits, one barrier per tile, two tiles
+//     in flight across it (no register staging, no ds_write pass);
+//   * per tile a wave issues its 8 K fragment reads up front, runs 16 score MFMAs, the two softmaxes, and 16 PV MFMAs
+//     whose V fragments (hardware-transposed reads) are shared by both query tiles;
+//   * 1-D grid, XCD-aware item order: the query blocks of an (image, head) run on the XCD whose L2 already holds its
+//     K and V.
+// Same arithmetic as attention_16_kernel (raw-score maximum, scale folded into the exp2 FMA, exact rescale only when a
+// maximum moved), so the two agree to rounding.
+template <typename HT>
+__global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
+                                                                   int D, int n_img) {
+    typedef typename Vec16<HT>::x8 hx8;
+    typedef typename Vec16<HT>::x4 hx4;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STAGE = 2 * 64 * 128;                      // K tile then V tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 15, g = lane >> 4;
+    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, per = (items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= items) return;
+    const int pair = item / nqb;
+    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 128 + 32 * wave;
+    const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
+    const unsigned row_bytes = 6u * (unsigned)D;
+    const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 128u;
+    const unsigned k_off = head_off + 2u * (unsigned)D, v_off = head_off + 4u * (unsigned)D;
+
+    // this wave's four LDS-DMA copies per key tile: rows 16 wave .. 16 wave + 15 of the K image (swizzled source
+    // chunk) and of the V image (linear), 8 rows per copy
+    const int r8 = lane >> 3;
+    unsigned koff[2], voff[2];
+    int krow[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        krow[c] = 16 * wave + 8 * c + r8;
+        koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7));
+        voff[c] = v_off + 16u * (unsigned)(lane & 7);
+    }
+    const int ntiles = (N + 63) >> 6;
+    auto issue = [&](int t) {
+        unsigned char* dst = smem + (t % 3) * STAGE + (16 * wave) * 128;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned ro = (unsigned)min(64 * t + krow[c], N - 1) * row_bytes;
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] + ro)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] + ro)), (lds_ptr)(dst + 64 * 128 + c * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    if (ntiles > 1) issue(1);
+    // Q fragments by ordinary loads AFTER the first copies, and consumed (empty asm) before the loop: hipcc places its
+    // wait for an ordinary load at the first use, and inside the tile loop that wait would be vmcnt(0) on every
+    // iteration, draining the LDS-DMA ring; here it is one wait in the prologue, which tile 0 needs anyway.
+    u32x4 qraw[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned o = head_off + (unsigned)min(q0 + 16 * j + qi, N - 1) * row_bytes + 16u * (unsigned)g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qraw[j][s] = *reinterpret_cast<const u32x4*>(qb + (o + 64u * s));
+    }
+    asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[1][0]), "+v"(qraw[1][1]));
+    hx8 qf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[j][s] = __builtin_bit_cast(hx8, qraw[j][s]);
+
+    f32x4 acc_o[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        m_run[j] = -INFINITY;
+        l_run[j] = 0.f;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) acc_o[j][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_vmcnt4();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // tile t has landed for every wave; everyone is done with tile t - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) issue(t + 2);
+        const unsigned char* ldsK = smem + (t % 3) * STAGE;
+        const lds_u8* vtr = (const lds_u8*)(ldsK + 64 * 128) + (4 * g + (qi >> 2)) * 128 + 8 * (qi & 3);
+        const int kb = t * 64;
+        hx8 kf[4][2];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                kf[t4][s] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
+        f32x4 acc_s[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                acc_s[j][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc_s[j][t4] = mfma16(kf[t4][s], qf[j][s], acc_s[j][t4]);
+            }
+        if (kb + 64 > N) {                              // keys beyond N: only the last tile has any (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb + 16 * t4 + 4 * g + r >= N) acc_s[j][t4][r] = -INFINITY;
+        }
+        // V fragments (hardware-transposed reads), requested now and consumed after the softmaxes.  Inline asm: for the
+        // ds_read_tr16 builtin hipcc waits vmcnt(0) first (it cannot tell the LDS-DMA copies in flight apart from the
+        // image being read), which would drain the ring on every tile; the reads' completion is waited for by hand.
+        s16x4 vlo[2][4], vhi[2][4];
+        {
+            const unsigned va = (unsigned)(size_t)vtr;
+#define VITVS_TR(dst, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(OFF))
+            VITVS_TR(vlo[0][0], 0);    VITVS_TR(vhi[0][0], 2048);      VITVS_TR(vlo[0][1], 32);   VITVS_TR(vhi[0][1], 2048 + 32);
+            VITVS_TR(vlo[0][2], 64);   VITVS_TR(vhi[0][2], 2048 + 64); VITVS_TR(vlo[0][3], 96);   VITVS_TR(vhi[0][3], 2048 + 96);
+            VITVS_TR(vlo[1][0], 4096); VITVS_TR(vhi[1][0], 6144);      VITVS_TR(vlo[1][1], 4128); VITVS_TR(vhi[1][1], 6144 + 32);
+            VITVS_TR(vlo[1][2], 4160); VITVS_TR(vhi[1][2], 6144 + 64); VITVS_TR(vlo[1][3], 4192); VITVS_TR(vhi[1][3], 6144 + 96);
+#undef VITVS_TR
+        }
+        hx8 pf[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float mloc = fmaxf(fmaxf(acc_s[j][0][0], acc_s[j][0][1]), fmaxf(acc_s[j][0][2], acc_s[j][0][3]));
+#pragma unroll
+            for (int t4 = 1; t4 < 4; ++t4)
+                mloc = fmaxf(mloc, fmaxf(fmaxf(acc_s[j][t4][0], acc_s[j][t4][1]), fmaxf(acc_s[j][t4][2], acc_s[j][t4][3])));
+            mloc = rows_max(mloc) * kScaleLog2e;
+            const float m_new = fmaxf(m_run[j], mloc);
+            const float neg_m = -m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(__builtin_fmaf(acc_s[j][t4][r], kScaleLog2e, neg_m));
+                    acc_s[j][t4][r] = p;
+                    psum += p;
+                }
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[j]) != 0ull) {
+                const float alpha = fast_exp2(m_run[j] - m_new);
+                l_run[j] *= alpha;
+#pragma unroll
+                for (int td = 0; td < 4; ++td) acc_o[j][td] *= alpha;
+                m_run[j] = m_new;
+            }
+            l_run[j] += psum;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[j][u][jj] = (HT)acc_s[j][2 * u + (jj >> 2)][jj & 3];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
+                       "+v"(vlo[0][3]), "+v"(vhi[0][3]), "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
+                       "+v"(vlo[1][2]), "+v"(vhi[1][2]), "+v"(vlo[1][3]), "+v"(vhi[1][3]));
+        __builtin_amdgcn_sched_barrier(0);
+        // O^T += V^T P^T for both query tiles; k-slot (g, jj) of step u  <->  key 32u + 16(jj>>2) + 4g + (jj&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const s16x4 lo = vlo[u][td], hi = vhi[u][td];
+                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc_o[j][td] = mfma16(__builtin_bit_cast(hx8, v8), pf[j][u], acc_o[j][td]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float inv = 1.0f / rows_sum(l_run[j]);
+        const int q = q0 + 16 * j + qi;
+        if (q < N) {
+            HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const hx4 o = {(HT)(acc_o[j][td][0] * inv), (HT)(acc_o[j][td][1] * inv), (HT)(acc_o[j][td][2] * inv),
+                               (HT)(acc_o[j][td][3] * inv)};
+                store_out<false>(dst + 16 * td, o);
+            }
         }
     }
 }
@@ -465,6 +662,9 @@ static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H,
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
                out, N, D, n_img);
+    } else if (N >= 512 && (long)n_img * N * 6 * D < (1l << 32)) {
+        const int items = ((N + 127) / 128) * H * n_img;
+        launch(attention_16_long_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 3 * 2 * 64 * 128, stream, qkv, out, N, D, n_img);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
     } else {

@@ -281,6 +281,13 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;
+    if (const int bn = big_tile_width(p, M, N, K, 1)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream);
+    return launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, stream);
+}
+
+int launch_linear_classic(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                          int gelu, hipStream_t stream) {
+    if (!shapes_ok(p, M, N, K)) return -2;
     const EpiArgs e{out, bias, nullptr, gelu};
     if (p == PREC_F32) return launch_tiles<float, EpiStore<float>>((const float*)A, (const float*)W, M, N, K, e, stream);
     if (p == PREC_F16) return launch_tiles<f16, EpiStore<f16>>((const f16*)A, (const f16*)W, M, N, K, e, stream);
@@ -311,6 +318,14 @@ int splitk_slices(Precision p, int M, int N, int K) {
 
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
                           hipStream_t stream) {
+    if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
+    if (const int bn = big_tile_width(p, M, N, K, splits))
+        return launch_linear_big(p, bn, A, W, nullptr, part, M, N, K, splits, 0, true, stream);
+    return launch_linear_partial_classic(p, A, W, part, M, N, K, splits, stream);
+}
+
+int launch_linear_partial_classic(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
+                                  hipStream_t stream) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
     const EpiArgs e{part, nullptr, nullptr, 0};
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);

@@ -1,0 +1,383 @@
+// Many-row linear layers (several frame pairs per call, 448² / 518² inputs: M = 2.7k ... 6.3k rows) on 256-row tiles.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        (both operands K-contiguous, 16-bit operands, fp32 accumulate)
+//
+// The 128x128 / 4-wave tile of gemm_core.h is bound by the CU's LDS fill path at these sizes (one 128-byte
+// row of operand per 128 MFMA-lanes of work: profiles/r01_notes.md).  This kernel doubles the tile edge (half the
+// operand bytes per FLOP) and runs the 8 waves of a workgroup as two groups that alternate between a LOAD segment (LDS
+// fragment reads + LDS-DMA issue) and an MFMA segment, one barrier apart, so that each SIMD's matrix pipe always has
+// one of its two waves in an MFMA segment.
+//
+// Tile: 8 waves as WGM x WGN, each wave MT x NT MFMA tiles of 16x16 (v_mfma_f32_16x16x32_{bf16,f16}); BM = WGM*MT*16,
+// BN = WGN*NT*16; k-tile = 64 elements = 128 bytes per row.  A k-tile is held as four "half slots": A0 / A1 = the rows
+// every wave reads for the first / second half of its m-tiles, B0 / B1 likewise for its n-tiles.  A k-tile's 4 phases
+// multiply the quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0) of every wave's tile.  LDS = 2 stages x 4 slots.
+//
+// Pipeline (per wave; LA / LB = LDS-DMA instructions per wave per A / B slot):
+//   * slot read in phase q is refilled in phase q + 2 (every wave has passed two barriers since its reads of q were
+//     issued, and one since they returned), with the k-tile two ahead:
+//       phase (j,0): B1(j+1)   (j,1): A1(j+1)   (j,2): A0(j+2)   (j,3): B0(j+2)
+//   * a slot is read no earlier than two barriers after every wave's counted wait that retires its copies: the wait at
+//     the end of each LOAD segment leaves the 2 LA + 2 LB youngest copies in flight (4 half slots = one k-tile of
+//     prefetch distance, ~4 phases of latency budget per copy); the last two k-tiles use the reduced counts derived in
+//     `k_tile()` below.
+//   * waves 4-7 run one barrier behind waves 0-3 (one extra barrier before their loop, one after for waves 0-3).
+// The swizzle of the LDS image (tile128_off) is applied to the per-lane SOURCE chunk (LDS-DMA writes linearly).
+// Epilogue: the accumulators go through a wave-private LDS image (all k-tile slots are dead by then) so that every
+// store instruction writes whole 128-byte (16-bit output) or 256-byte (fp32 partial sums) row segments.
+#include <algorithm>
+
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vitvs {
+
+template <int WGM_, int WGN_, int MT_, int NT_>
+struct BigTile {
+    static constexpr int WGM = WGM_, WGN = WGN_, MT = MT_, NT = NT_;
+    static constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
+    static constexpr int AH = (MT / 2) * 16, BH = (NT / 2) * 16;       // rows of one wave in a half slot
+    static constexpr int A_ROWS = WGM * AH, B_ROWS = WGN * BH;        // rows of a half slot
+    static constexpr int LA = A_ROWS / 64, LB = B_ROWS / 64;          // LDS-DMA instructions per wave per slot (8 waves x 8 rows)
+    static constexpr int A_SLOT = A_ROWS * 128, B_SLOT = B_ROWS * 128;
+    static constexpr int STAGE = 2 * A_SLOT + 2 * B_SLOT;
+    static constexpr int RING = 2 * STAGE;
+    static constexpr int WAVE_REGION = RING / 8;                      // epilogue image of one wave
+    static constexpr int LDS_BYTES = RING;
+    static_assert(WGM * WGN == 8 && MT % 2 == 0 && NT % 2 == 0, "8 waves, even tile counts");
+    static_assert(A_ROWS % 64 == 0 && B_ROWS % 64 == 0, "a half slot is a whole number of 8-row copies per wave");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// epilogue policies: what is added / applied to the fp32 sums and what is stored
+template <typename T>
+struct BigStore {      // out[m][n] = act(sum + bias[n]) in the operand type
+    typedef T Out;
+    T* out;
+    const float* bias;
+    int ldo, gelu;
+    __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ __forceinline__ f32x4 apply(f32x4 v, float4 b) const {
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26), as linear_kernel's 16-bit epilogue
+                const float x = fabsf(v[i]) * 0.70710678118654752440f;
+                const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+                const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+                const float e = 1.0f - poly * __expf(-x * x);
+                v[i] = 0.5f * v[i] * (1.0f + copysignf(e, v[i]));
+            }
+        }
+        return v;
+    }
+};
+struct BigPartial {    // part[z][m][n] = raw fp32 sums of k slice z
+    typedef float Out;
+    float* out;
+    int ldo;
+    __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ f32x4 apply(f32x4 v, float4) const { return v; }
+};
+
+template <typename T, class Tile, class Epi>
+__global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                           typename Epi::Out* __restrict__ out, const float* __restrict__ bias,
+                                                           int M, int N, int K, int flags, int slots) {
+    // flags: [31:24] k-tiles per split-K slice, [23:16] column tiles, [15:8] slices, [0] gelu.  PERSISTENT workgroups:
+    // a 1-D grid of `slots` (a multiple of 8, at most one per CU) workgroups; workgroup i runs on XCD i % 8 (its own
+    // L2); XCD x owns the x-th eighth of the (slice, row tile, column tile) list, column fastest — a few A row panels
+    // and the weight panels of one slice — and its slots / 8 workgroups walk that eighth with stride slots / 8.  A
+    // tile's output stores drain while the workgroup already requests the next tile's operands, and workgroups drift
+    // apart, so the chip's store bursts no longer coincide (one bulk-synchronous round per tile measured 9 us of fixed
+    // cost per round at 6274 x 2304: profiles/r02_notes.md).
+    constexpr int MT = Tile::MT, NT = Tile::NT, WGN = Tile::WGN;
+    constexpr int LA = Tile::LA, LB = Tile::LB, FULL = 2 * LA + 2 * LB;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned fl = (unsigned)flags;
+    const int nk = (int)(fl >> 24), nx = (int)((fl >> 16) & 255), nz = (int)((fl >> 8) & 255);
+    const int ny = (M + Tile::BM - 1) / Tile::BM;
+    const int tiles = nx * ny * nz, per = (tiles + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7), stride = slots >> 3;
+    const int lin_end = min((xcd + 1) * per, tiles);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WGN, wc = wave - wr * WGN;     // waves 0 .. 3 and 4 .. 7 are the two staggered groups
+    const int l15 = lane & 15, g = lane >> 4;
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
+    bool first_tile = true;
+  for (int lin = xcd * per + (int)(blockIdx.x >> 3); lin < lin_end; lin += stride) {
+    const int tz = lin / (nx * ny), rem = lin - tz * nx * ny;
+    const int ty = rem / nx, tx = rem - ty * nx;
+    const int m0 = ty * Tile::BM, n0 = tx * Tile::BN, k0 = tz * nk * 64;
+    if (!first_tile) {
+        // every wave has read its epilogue image back (its stores are issued): the ring may be overwritten
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    first_tile = false;
+
+    // ---- LDS-DMA sources: per slot kind (A0, A1, B0, B1) and copy j, a 32-bit byte offset from A / W
+    unsigned offA[2][LA], offB[2][LB];
+    {
+        const int r8 = lane >> 3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int rs = (wave * LA + j) * 8 + r8;                          // row inside the slot
+                const int w_ = rs / Tile::AH, ml = rs - w_ * Tile::AH;
+                const int row = min(m0 + w_ * (MT * 16) + h * Tile::AH + ml, M - 1);
+                const int c = (lane & 7) ^ ((rs >> 1) & 7);
+                offA[h][j] = (unsigned)row * (unsigned)K * (unsigned)sizeof(T) + (unsigned)k0 * (unsigned)sizeof(T) + c * 16;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int rs = (wave * LB + j) * 8 + r8;
+                const int w_ = rs / Tile::BH, nl = rs - w_ * Tile::BH;
+                const int row = n0 + w_ * (NT * 16) + h * Tile::BH + nl;          // N is a multiple of BN
+                const int c = (lane & 7) ^ ((rs >> 1) & 7);
+                offB[h][j] = (unsigned)row * (unsigned)K * (unsigned)sizeof(T) + (unsigned)k0 * (unsigned)sizeof(T) + c * 16;
+            }
+        }
+    }
+    auto slot = [&](int stage, int kind) -> unsigned char* {   // kind: 0 A0, 1 A1, 2 B0, 3 B1
+        return smem + stage * Tile::STAGE + (kind < 2 ? kind * Tile::A_SLOT : 2 * Tile::A_SLOT + (kind - 2) * Tile::B_SLOT);
+    };
+    auto issue_a = [&](int h, int kt) {
+        unsigned char* dst = slot(kt & 1, h) + wave * LA * 1024;
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (offA[h][j] + (unsigned)kt * 128u)), (lds_ptr)(dst + j * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int h, int kt) {
+        unsigned char* dst = slot(kt & 1, 2 + h) + wave * LB * 1024;
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wb + (offB[h][j] + (unsigned)kt * 128u)), (lds_ptr)(dst + j * 1024), 16, 0, 0);
+    };
+
+    Epi epi;
+    epi.out = out;
+    epi.ldo = N;
+    if constexpr (!__is_same(Epi, BigPartial)) { epi.bias = bias; epi.gelu = (int)(fl & 1u); }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: k-tile 0 whole, k-tile 1's first halves, in the steady-state order
+    issue_a(0, 0); issue_b(0, 0); issue_b(1, 0); issue_a(1, 0);
+    issue_a(0, 1); issue_b(0, 1);
+    wait_vmcnt<FULL>();                                  // A0(0), B0(0) have landed (this wave's copies)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                        // ... and every other wave's
+    if (wave >= 4) __builtin_amdgcn_s_barrier();         // stagger: the second group runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment registers: the current A half, both B halves
+    u32x4 xa[MT / 2][2], wb[2][NT / 2][2];
+    const int a_row = wr * Tile::AH + l15, b_row = wc * Tile::BH + l15;
+    auto read_a = [&](int stage, int h) {
+        const unsigned char* s = slot(stage, h);
+#pragma unroll
+        for (int mi = 0; mi < MT / 2; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xa[mi][ks] = *reinterpret_cast<const u32x4*>(s + tile128_off(a_row + mi * 16, 4 * ks + g));
+    };
+    auto read_b = [&](int stage, int h) {
+        const unsigned char* s = slot(stage, 2 + h);
+#pragma unroll
+        for (int ni = 0; ni < NT / 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wb[h][ni][ks] = *reinterpret_cast<const u32x4*>(s + tile128_off(b_row + ni * 16, 4 * ks + g));
+    };
+    auto mfma_quadrant = [&](int ha, int hb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NT / 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT / 2; ++mi)
+                    acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi] =
+                        mma_chunk<T>(acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi], wb[hb][ni][ks], xa[mi][ks]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase = LOAD segment | barrier | MFMA segment | barrier
+#define VITVS_BIG_PHASE(READS, ISSUE, WAITN, HA, HB)                 \
+    do {                                                              \
+        READS;                                                        \
+        ISSUE;                                                        \
+        wait_vmcnt<WAITN>();                                          \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        __builtin_amdgcn_s_barrier();                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        mfma_quadrant(HA, HB);                                        \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        __builtin_amdgcn_s_barrier();                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+
+    // k_tile(j): counts of copies that may stay in flight at each phase's wait (see the header):
+    //   phase 0 retires B1(j): younger copies A1(j) + k-tile j+1's A0, B0, B1            -> FULL, or LA when j + 1 == nk
+    //   phase 1 retires A1(j): younger copies k-tile j+1's A0, B0, B1, A1                -> FULL, or 0
+    //   phase 3 retires A0(j+1), B0(j+1): younger B1(j+1), A1(j+1), A0(j+2), B0(j+2)     -> FULL, or LA + LB when j + 2 == nk
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        const int st = kt & 1;
+        VITVS_BIG_PHASE((read_a(st, 0), read_b(st, 0)), issue_b(1, kt + 1), FULL, 0, 0);
+        VITVS_BIG_PHASE(read_b(st, 1), issue_a(1, kt + 1), FULL, 0, 1);
+        VITVS_BIG_PHASE(read_a(st, 1), issue_a(0, kt + 2), FULL, 1, 1);
+        VITVS_BIG_PHASE((void)0, issue_b(0, kt + 2), FULL, 1, 0);
+    }
+    {   // kt == nk - 2: nothing left to request in phases 2 and 3
+        const int st = kt & 1;
+        VITVS_BIG_PHASE((read_a(st, 0), read_b(st, 0)), issue_b(1, kt + 1), FULL, 0, 0);
+        VITVS_BIG_PHASE(read_b(st, 1), issue_a(1, kt + 1), FULL, 0, 1);
+        VITVS_BIG_PHASE(read_a(st, 1), (void)0, FULL, 1, 1);
+        VITVS_BIG_PHASE((void)0, (void)0, LA + LB, 1, 0);
+        ++kt;
+    }
+    {   // kt == nk - 1
+        const int st = kt & 1;
+        VITVS_BIG_PHASE((read_a(st, 0), read_b(st, 0)), (void)0, LA, 0, 0);
+        VITVS_BIG_PHASE(read_b(st, 1), (void)0, 0, 0, 1);
+        VITVS_BIG_PHASE(read_a(st, 1), (void)0, 0, 1, 1);
+        VITVS_BIG_PHASE((void)0, (void)0, 0, 1, 0);
+    }
+#undef VITVS_BIG_PHASE
+    if (wave < 4) __builtin_amdgcn_s_barrier();          // the first group's matching extra barrier
+    __builtin_amdgcn_sched_barrier(0);
+    // every wave has passed its last LDS read and every copy has landed (vmcnt 0 above): the ring is free
+
+    // ---- epilogue through a wave-private LDS image, then whole-row stores
+    // (lane-dependent addresses are rebuilt from an opaque copy of the lane id: hoisted out of the tile loop they
+    // would be spilled around the k-loop, and a spill reload's vmcnt(0) serialises the LDS-DMA prologue)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l15e = lane_e & 15, ge = lane_e >> 4;
+    typedef typename Epi::Out O;
+    constexpr int ES = (int)sizeof(O);
+    constexpr int ROW_BYTES = NT * 16 * ES;                        // 128 (16-bit, NT = 4), 256 (fp32, NT = 4), ...
+    constexpr int CHUNKS = ROW_BYTES / 16;                         // 16-byte chunks per row (a power of two)
+    constexpr int PASS_MT = (MT * 16 * ROW_BYTES <= Tile::WAVE_REGION) ? MT : MT / 2;
+    static_assert(PASS_MT * 16 * ROW_BYTES <= Tile::WAVE_REGION, "epilogue image does not fit");
+    static_assert((CHUNKS & (CHUNKS - 1)) == 0 && CHUNKS <= 64, "row chunks");
+    // per-column terms (bias): requested here rather than before the k-loop — 16 registers the loop cannot spare
+    float4 col[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) col[ni] = epi.column_terms(n0 + wc * (NT * 16) + ni * 16 + 4 * ge);
+    unsigned char* img = smem + wave * Tile::WAVE_REGION;
+    O* obase = out + (size_t)tz * M * N;
+    const int wm0 = m0 + wr * (MT * 16), wn0 = n0 + wc * (NT * 16);
+    constexpr int ROWS_PER_INST = 64 / CHUNKS;                     // rows one 64-lane 16-byte access covers
+#pragma unroll
+    for (int pass = 0; pass < MT / PASS_MT; ++pass) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int mp = 0; mp < PASS_MT; ++mp) {
+                const int mi = pass * PASS_MT + mp;
+                const f32x4 v = epi.apply(acc[ni][mi], col[ni]);
+                const int row = mp * 16 + l15e;
+                if constexpr (ES == 4) {
+                    const int chunk = ni * 4 + ge;
+                    *reinterpret_cast<f32x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4)) = v;
+                } else {
+                    const int chunk = ni * 2 + (ge >> 1);
+                    const typename Vec16<O>::x4 h = {(O)v[0], (O)v[1], (O)v[2], (O)v[3]};
+                    *reinterpret_cast<typename Vec16<O>::x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4) + (ge & 1) * 8) = h;
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image is this wave's own: no barrier
+        __builtin_amdgcn_sched_barrier(0);
+        // whole rows back from the image, 8 reads in flight before their stores
+        constexpr int NI = PASS_MT * 16 / ROWS_PER_INST, BATCH = NI < 8 ? NI : 8;
+#pragma unroll
+        for (int b0 = 0; b0 < NI; b0 += BATCH) {
+            u32x4 rowv[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int row = (b0 + i) * ROWS_PER_INST + lane_e / CHUNKS, chunk = lane_e & (CHUNKS - 1);
+                rowv[i] = *reinterpret_cast<const u32x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int row = (b0 + i) * ROWS_PER_INST + lane_e / CHUNKS, chunk = lane_e & (CHUNKS - 1);
+                const int m = wm0 + pass * PASS_MT * 16 + row;
+                if (m < M) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0) + chunk * 16) = rowv[i];
+            }
+        }
+        if (pass + 1 < MT / PASS_MT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }   // next tile of this workgroup
+}
+
+// ---------------------------------------------------------------------------------------------------- launch side
+typedef BigTile<2, 4, 8, 4> Tile256x256;
+typedef BigTile<4, 2, 4, 4> Tile256x128;
+
+template <typename T, class Tile, class Epi>
+static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const float* bias, int M, int N, int K, int splits,
+                          int gelu, hipStream_t stream) {
+    static std::atomic<unsigned long long> raised{0};
+    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_big_kernel<T, Tile, Epi>), Tile::LDS_BYTES, raised)) return -1;
+    const int nx = N / Tile::BN, ny = (M + Tile::BM - 1) / Tile::BM, nk = K / splits / 64;
+    if (N % Tile::BN || K % (splits * 64) || nk < 2 || nk > 255 || nx > 255 || splits > 255) return -2;
+    const long tiles = (long)nx * ny * splits;
+    const int slots = (int)std::min<long>(8 * ((tiles + 7) / 8), 256);       // one workgroup per CU at most
+    launch(linear_big_kernel<T, Tile, Epi>, dim3((unsigned)slots), dim3(512), Tile::LDS_BYTES, stream, A, W, out, bias, M, N, K,
+           (int)(((unsigned)nk << 24) | ((unsigned)nx << 16) | ((unsigned)splits << 8) | (unsigned)(gelu & 1)), slots);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Which tile family for a many-row problem.  Measured on MI355X (tools/big_ops, random bf16 data, profiles/r02_big_ops.txt):
+// in its k-loop the 256x256 tile sustains ~1.5 PFLOP/s chip-wide, so what decides is how well the tile count fills the 256
+// CUs and the fixed cost per round (operand latency at the start, the output burst at the end: ~9 us at 6274 x 2304):
+//   * 120 .. 256 tiles of 256x256: one round, well filled                        -> 256x256
+//     (6274x2304: 24 us vs 27 (256x128) / 35 (gemm.hip); 3152x3072: 26 / 30 / 31; 2740x4096x1024: 31 / 36 / 36)
+//   * otherwise, >= 96 tiles of 256x128 (each CU walks its 1 .. 3 tiles)            -> 256x128
+//     (6274x3072: 46 vs 50 / 49; 6274x768x3072: 38 vs 55 / 46; 3152x2304: 16 vs 21 / 19; 788x3072: 15 vs 23 / 20)
+//   * fewer tiles than that (narrow layers at 3152 / 2740 rows): the 2-workgroups-per-CU tiles of gemm.hip win or tie.
+// Returns 0 (use gemm.hip), 256 or 128.
+int big_tile_width(Precision p, int M, int N, int K, int splits) {
+    if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
+    const long ny = (M + 255) / 256;
+    if (N % 256 == 0 && N / 256 <= 255) {
+        const long t256 = ny * (N / 256) * splits;
+        if (t256 >= 120 && t256 <= 256) return 256;
+    }
+    if (N % 128 == 0 && N / 128 <= 255 && ny * (N / 128) * splits >= 96) return 128;
+    return 0;
+}
+
+template <typename T>
+static int launch_big_t(int bn, const T* A, const T* W, const float* bias, void* out, int M, int N, int K, int splits, int gelu,
+                        bool partial, hipStream_t stream) {
+    if (partial) {
+        if (bn == 256) return launch_big_one<T, Tile256x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+        return launch_big_one<T, Tile256x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+    }
+    if (bn == 256) return launch_big_one<T, Tile256x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+    return launch_big_one<T, Tile256x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+}
+
+int launch_linear_big(Precision p, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                      int splits, int gelu, bool partial, hipStream_t stream) {
+    if ((long long)M * K * 2 >= (1ll << 32) || (long long)N * K * 2 >= (1ll << 32)) return -2;   // 32-bit operand offsets
+    if (p == PREC_BF16) return launch_big_t<bf16>(bn, (const bf16*)A, (const bf16*)W, bias, out, M, N, K, splits, gelu, partial, stream);
+    if (p == PREC_F16) return launch_big_t<f16>(bn, (const f16*)A, (const f16*)W, bias, out, M, N, K, splits, gelu, partial, stream);
+    return -2;
+}
+
+}  // namespace vitvs

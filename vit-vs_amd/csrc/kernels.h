@@ -61,6 +61,11 @@ inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
 // out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]); A, W, out in precision p; gelu: erf GELU.
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream);
+// the same two operators restricted to the tiles of gemm.hip (no hand-over to gemm_big.hip)
+int launch_linear_classic(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                          int gelu, hipStream_t stream);
+int launch_linear_partial_classic(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
+                                  hipStream_t stream);
 // x[m][n] += ls[n] * (sum_k A[m][k] W[n][k] + bias[n]); x fp32 residual stream, ls may be null.
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
                            int M, int N, int K, hipStream_t stream);
@@ -72,6 +77,13 @@ int launch_linear_partial(Precision p, const void* A, const void* W, float* part
 // x[img*(T+1) + 1 + t][n] = sum_k Ape[img*T + t][k] Wpe[n][k] + bias[n] + pos[1 + t][n]
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
                        int n_img, int T, int D, int Kp, hipStream_t stream);
+
+// ---- gemm_big.hip: 256-row tiles for many-row problems (16-bit operands) --------------------------------
+// big_tile_width: 0 = not applicable (use the tiles of gemm.hip), else the column-tile width (256 or 128) to pass on.
+int big_tile_width(Precision p, int M, int N, int K, int splits);
+// partial = false: out[m][n] = act(sum + bias[n]) in precision p; partial = true: out = fp32 part[z][m][n], z < splits.
+int launch_linear_big(Precision p, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                      int splits, int gelu, bool partial, hipStream_t stream);
 
 // ---- elementwise.hip -----------------------------------------------------------------------
 struct PatchifyArgs {
