@@ -726,7 +726,8 @@ def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
                                  selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
     det = eng.last_details(1)
     assert int(st[0]) == 0 and int(det["info"][0, 2]) == 1          # same_image flag
-    assert np.array_equal(det["s_uv"][0, :, :2], det["s_uv"][0, :, 2:])
+    k = params.num_pairs                                             # rows beyond num_pairs belong to larger calls (max_rows = 48)
+    assert np.array_equal(det["s_uv"][0, :k, :2], det["s_uv"][0, :k, 2:])
     assert np.all(v.cpu().numpy() == 0.0)
 
 

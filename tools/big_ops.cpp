@@ -2,6 +2,8 @@
 // the data): each linear layer of the many-row configurations on every tile family, and the long-sequence attention.
 // Build: make -C tools      Run: HIP_FORCE_DEV_KERNARG=1 tools/big_ops [fast]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,8 +73,10 @@ int main(int argc, char** argv) {
     };
     const int nsets = 4;
     printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, classic, 256x256, 256x128");
+    const bool attn_only = argc > 1 && !strcmp(argv[1], "attn");
     std::vector<Shape> todo;
-    if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
+    if (attn_only) todo.clear();
+    else if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
     else todo.assign(std::begin(shapes), std::end(shapes));
     for (const Shape& s : todo) {
         void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
@@ -109,6 +113,29 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&out, (size_t)n_img * N * D * 2));
         const double us = run(st, fast ? 10 : 30, [&] { return vitvs_op_attention(VITVS_BF16, qkv, out, n_img, N, H, st); });
         printf("attention %d x %d tokens x %d heads: %8.1f us  %6.0f TFLOP/s\n", n_img, N, H, us, 4.0 * n_img * N * (double)N * D / us * 1e-6);
+        // probe builds of the library (-DVITVS_PROBE) export a hook: per-wave cycle sums of the long kernel's tile loop
+        typedef int (*set_probe_t)(void*);
+        set_probe_t set_probe = (set_probe_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_attn_probe");
+        if (set_probe && N >= 512) {
+            const int wgs = 8 * ((((N + 127) / 128) * H * n_img + 7) / 8);
+            unsigned long long* buf;
+            CHECK(hipMalloc((void**)&buf, (size_t)wgs * 4 * 8 * 8));
+            CHECK(hipMemset(buf, 0, (size_t)wgs * 4 * 8 * 8));
+            set_probe(buf);
+            for (int i = 0; i < 3; ++i) vitvs_op_attention(VITVS_BF16, qkv, out, n_img, N, H, st);
+            CHECK(hipStreamSynchronize(st));
+            set_probe(nullptr);
+            std::vector<unsigned long long> hbuf((size_t)wgs * 4 * 8);
+            CHECK(hipMemcpy(hbuf.data(), buf, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> col[8];
+            for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * 8 + 7]) for (int k = 0; k < 8; ++k) col[k].push_back((double)hbuf[(size_t)w * 8 + k]);
+            auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            const double nt = med(col[7]);
+            printf("  probe (median over %zu waves, cycles per tile): wait-dma %.0f  barrier %.0f  issue+K-reads+QK %.0f  softmax %.0f  tr-wait+PV %.0f | total %.0f cycles in %.1f us -> %.2f GHz\n",
+                   col[0].size(), med(col[0]) / nt, med(col[1]) / nt, med(col[2]) / nt, med(col[3]) / nt, med(col[4]) / nt, med(col[5]), med(col[6]) / 100.0,
+                   med(col[5]) / (med(col[6]) * 10.0));
+            CHECK(hipFree(buf));
+        }
         CHECK(hipFree(qkv)); CHECK(hipFree(out));
     }
     return 0;

@@ -139,6 +139,7 @@ int dev_alloc(vitvs_handle* h, T** out, size_t count) {
     hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc", __FILE__, __LINE__);
     h->allocs.push_back(p);
+    (void)hipMemset(p, 0, count * sizeof(T) + 256);   // detail rows a call does not write read as zeros, not as stale memory
     *out = reinterpret_cast<T*>(p);
     return 0;
 }

@@ -30,6 +30,24 @@ constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * lo
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
 __device__ __forceinline__ void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// max of three as ONE instruction: for fmaxf() on MFMA results hipcc first emits a canonicalising v_max_f32 x, x, x per
+// operand (32 extra vector instructions per key tile in a loop that is bound by vector issue)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max of the 16 scores a lane holds for one query tile: 8 instructions
+__device__ __forceinline__ float max16(const f32x4 (&s)[4]) {
+    float m = max3(s[0][0], s[0][1], s[0][2]);
+    m = max3(m, s[0][3], s[1][0]);
+    m = max3(m, s[1][1], s[1][2]);
+    m = max3(m, s[1][3], s[2][0]);
+    m = max3(m, s[2][1], s[2][2]);
+    m = max3(m, s[2][3], s[3][0]);
+    m = max3(m, s[3][1], s[3][2]);
+    return max3(m, s[3][3], s[3][3]);
+}
 
 // ------------------------------------------------------------------------------------ bf16
 template <typename HT, int KS>
@@ -200,18 +218,36 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
 
 // ------------------------------------------------------------------------------------ 16-bit, long sequences
 // N >= 512 (448² / 518² inputs: 3137 / 1370 tokens).  The 64-query kernel above is bound by the K / V traffic into LDS
-// (every 64 queries re-read the (image, head)'s whole K and V: 0.94 GB per launch at 3137 tokens) and by exposed LDS
-// latency (each MFMA waits for the fragment read issued just before it).  Here:
-//   * one workgroup = 128 queries, wave w = queries 32 w .. 32 w + 31 as two 16-query tiles that share every K and V
-//     fragment read (half the LDS traffic per MFMA, half the K / V traffic per query);
+// (every 64 queries re-read the (image, head)'s whole K and V: 0.94 GB per launch at 3137 tokens), by exposed LDS
+// latency (each MFMA waits for the fragment read issued just before it) and by vector-instruction issue.  Here:
+//   * one workgroup = 128 queries, wave w = queries 32 w .. 32 w + 31 on the 32x32x16 MFMA (half the MFMA issue slots of
+//     the 16x16x32 form for the same work, one softmax state per lane, one cross-lane step per reduction);
 //   * K / V tiles of 64 keys arrive by LDS-DMA into a 3-stage ring with counted waits, one barrier per tile, two tiles
 //     in flight across it (no register staging, no ds_write pass);
-//   * per tile a wave issues its 8 K fragment reads up front, runs 16 score MFMAs, the two softmaxes, and 16 PV MFMAs
-//     whose V fragments (hardware-transposed reads) are shared by both query tiles;
+//   * S^T = K Q^T per 32-key block leaves a lane with 16 scores of ONE query (column = lane & 31); the accumulator
+//     registers 8s .. 8s+7, converted pairwise, ARE the B operand of k-step s of O^T += V^T P^T (register index -> key map
+//     16s + 8(j>>2) + 4(lane>>5) + (j&3)), and the V fragments are fetched with hardware-transposed reads in that key order;
 //   * 1-D grid, XCD-aware item order: the query blocks of an (image, head) run on the XCD whose L2 already holds its
 //     K and V.
 // Same arithmetic as attention_16_kernel (raw-score maximum, scale folded into the exp2 FMA, exact rescale only when a
 // maximum moved), so the two agree to rounding.
+// Where the time goes (probe build, tools/big_ops attn, 3137 tokens, 2.0 GHz in-kernel clock; cycles per key tile of a
+// wave, 2-3 waves per SIMD): DMA wait 56, barrier 145, K reads + 8 score MFMAs 780, softmax 1500, V reads + 8 PV MFMAs 330.
+// The softmax is ~145 vector instructions per tile (32 each of fma / exp2 / add, 16 max3, 16 cvt_pk) at ~4 issue cycles
+// each per wave: with head dimension 64 a score costs 2 MFMA-k-steps but the same vector work as at 128, so the kernel
+// is bound by vector issue, not by the matrix pipe (profiles/r02_notes.md has the variants that did not move it:
+// 16x16x32 tiles, staggered workgroup starts, fewer address instructions).
+#ifdef VITVS_PROBE
+// probe builds only (tools/big_ops probe): per-wave cycle sums of the tile loop's parts + realtime span
+__device__ unsigned long long* g_attn_probe;
+#define VITVS_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VITVS_STAMP(var) do { } while (0)
+#endif
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
 template <typename HT>
 __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
                                                                    int D, int n_img) {
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE = 2 * 64 * 128;                      // K tile then V tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qi = lane & 15, g = lane >> 4;
+    const int r32 = lane & 31, hh = lane >> 5;
     const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, per = (items + 7) >> 3;
     const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (item >= items) return;
@@ -235,25 +271,41 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 128u;
     const unsigned k_off = head_off + 2u * (unsigned)D, v_off = head_off + 4u * (unsigned)D;
 
-    // this wave's four LDS-DMA copies per key tile: rows 16 wave .. 16 wave + 15 of the K image (swizzled source
-    // chunk) and of the V image (linear), 8 rows per copy
+    // this wave's four LDS-DMA copies per key tile: rows 16 wave .. 16 wave + 15 of the K image and of the V image, 8
+    // rows per copy, swizzled on the SOURCE chunk (LDS-DMA writes linearly):
+    //   K image: chunk c of row r at slot c ^ ((r >> 1) & 7)   (tile128_off: conflict-free ds_read_b128 of 32 rows)
+    //   V image: chunk c of row r at slot c ^ (((r >> 1) & 1) << 2): the 4 rows x two 32-byte windows a half-wave of a
+    //            transposed read touches then fall on 8 different 32-byte bank windows
     const int r8 = lane >> 3;
     unsigned koff[2], voff[2];
     int krow[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         krow[c] = 16 * wave + 8 * c + r8;
-        koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7));
-        voff[c] = v_off + 16u * (unsigned)(lane & 7);
+        koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7)) + (unsigned)krow[c] * row_bytes;
+        voff[c] = v_off + 16u * (unsigned)((lane & 7) ^ (((krow[c] >> 1) & 1) << 2)) + (unsigned)krow[c] * row_bytes;
     }
     const int ntiles = (N + 63) >> 6;
+    // source offsets advance by 64 rows per tile (one add per copy); only the last tile can reach past row N - 1 and
+    // takes the clamped form
+    const unsigned tile_bytes = 64u * row_bytes;
     auto issue = [&](int t) {
         unsigned char* dst = smem + (t % 3) * STAGE + (16 * wave) * 128;
+        if (t + 1 < ntiles) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const unsigned ro = (unsigned)min(64 * t + krow[c], N - 1) * row_bytes;
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] + ro)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] + ro)), (lds_ptr)(dst + 64 * 128 + c * 1024), 16, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + koff[c]), (lds_ptr)(dst + c * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + voff[c]), (lds_ptr)(dst + 64 * 128 + c * 1024), 16, 0, 0);
+                koff[c] += tile_bytes;
+                voff[c] += tile_bytes;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned back = __umul24((unsigned)max(64 * t + krow[c] - (N - 1), 0), row_bytes);   // rows past the end -> row N - 1
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] - back)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] - back)), (lds_ptr)(dst + 64 * 128 + c * 1024), 16, 0, 0);
+            }
         }
     };
     issue(0);
@@ -261,136 +313,166 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     // Q fragments by ordinary loads AFTER the first copies, and consumed (empty asm) before the loop: hipcc places its
     // wait for an ordinary load at the first use, and inside the tile loop that wait would be vmcnt(0) on every
     // iteration, draining the LDS-DMA ring; here it is one wait in the prologue, which tile 0 needs anyway.
-    u32x4 qraw[2][2];
+    // B operand of S^T = K Q^T: lane (r32, hh) holds Q[query r32][dims 16 ks + 8 hh + 0..7]
+    u32x4 qraw[4];
+    {
+        const unsigned o = head_off + (unsigned)min(q0 + r32, N - 1) * row_bytes + 16u * (unsigned)hh;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const unsigned o = head_off + (unsigned)min(q0 + 16 * j + qi, N - 1) * row_bytes + 16u * (unsigned)g;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qraw[j][s] = *reinterpret_cast<const u32x4*>(qb + (o + 64u * s));
+        for (int ks = 0; ks < 4; ++ks) qraw[ks] = *reinterpret_cast<const u32x4*>(qb + (o + 32u * ks));
     }
-    asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[1][0]), "+v"(qraw[1][1]));
-    hx8 qf[2][2];
+    asm volatile("" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]));
+    hx8 qf[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qf[j][s] = __builtin_bit_cast(hx8, qraw[j][s]);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(hx8, qraw[ks]);
 
-    f32x4 acc_o[2][4];
-    float m_run[2], l_run[2];
+    f32x16 acc_o[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        m_run[j] = -INFINITY;
-        l_run[j] = 0.f;
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int td = 0; td < 4; ++td) acc_o[j][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    // lane constants of the fragment reads
+    const int k_sw = (r32 >> 1) & 7;                              // K image swizzle of this lane's key row (32 kb + r32)
+    const int li = lane & 15, dh = (lane >> 4) & 1;              // transposed V read: lane li of a 16-lane group, dim half dh
+    const int v_row = 4 * hh + (li >> 2);                        // key row inside a 16-key step (+ 8 for elements 4..7)
+    const int v_sw = ((v_row >> 1) & 1) << 1;                    // window swizzle of that row (the 8-row step keeps bit 1)
+#ifdef VITVS_PROBE
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0};
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < ntiles; ++t) {
+        VITVS_STAMP(ts0);
         if (t + 1 < ntiles) wait_vmcnt4();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VITVS_STAMP(ts1);
         __builtin_amdgcn_s_barrier();                   // tile t has landed for every wave; everyone is done with tile t - 1
         __builtin_amdgcn_sched_barrier(0);
+        VITVS_STAMP(ts2);
         if (t + 2 < ntiles) issue(t + 2);
         const unsigned char* ldsK = smem + (t % 3) * STAGE;
-        const lds_u8* vtr = (const lds_u8*)(ldsK + 64 * 128) + (4 * g + (qi >> 2)) * 128 + 8 * (qi & 3);
-        const int kb = t * 64;
-        hx8 kf[4][2];
+        const int kb0 = t * 64;
+        // scores: acc_s[kb][i] = S[key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 hh][query r32]
+        f32x16 acc_s[2];
+        {
+            hx8 kf[2][4];                               // all 8 K fragment reads in flight before the first MFMA
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                kf[t4][s] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(ldsK + tile128_off(16 * t4 + qi, 4 * s + g)));
-        f32x4 acc_s[2][4];
+                for (int ks = 0; ks < 4; ++ks)
+                    kf[kb][ks] = __builtin_bit_cast(hx8, *reinterpret_cast<const u32x4*>(ldsK + (32 * kb + r32) * 128 + (((2 * ks + hh) ^ k_sw) << 4)));
+            __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks each read next to its MFMA: 8 exposed LDS latencies)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int kb = 0; kb < 2; ++kb) {
+                acc_s[kb] = mfma32(kf[kb][0], qf[0], zero);   // C = 0 is an inline constant of the instruction: no register zeroing
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                acc_s[j][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) acc_s[j][t4] = mfma16(kf[t4][s], qf[j][s], acc_s[j][t4]);
+                for (int ks = 1; ks < 4; ++ks) acc_s[kb] = mfma32(kf[kb][ks], qf[ks], acc_s[kb]);
             }
-        if (kb + 64 > N) {                              // keys beyond N: only the last tile has any (wave-uniform)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kb + 16 * t4 + 4 * g + r >= N) acc_s[j][t4][r] = -INFINITY;
         }
-        // V fragments (hardware-transposed reads), requested now and consumed after the softmaxes.  Inline asm: for the
+#ifdef VITVS_PROBE
+        asm volatile("s_nop 0" ::"v"(acc_s[0][0]), "v"(acc_s[1][15]) : "memory");
+#endif
+        VITVS_STAMP(ts3);
+        // V fragments (hardware-transposed reads), requested now and consumed after the softmax.  Inline asm: for the
         // ds_read_tr16 builtin hipcc waits vmcnt(0) first (it cannot tell the LDS-DMA copies in flight apart from the
         // image being read), which would drain the ring on every tile; the reads' completion is waited for by hand.
-        s16x4 vlo[2][4], vhi[2][4];
+        // vf[step][db][half]: A operand of k-step `step` (16 keys) for dim block db; element j <-> key 16 step + 8 (j >> 2)
+        // + 4 hh + (j & 3), dim 32 db + 16 dh + li
+        s16x4 vf[4][2][2];
         {
-            const unsigned va = (unsigned)(size_t)vtr;
-#define VITVS_TR(dst, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(OFF))
-            VITVS_TR(vlo[0][0], 0);    VITVS_TR(vhi[0][0], 2048);      VITVS_TR(vlo[0][1], 32);   VITVS_TR(vhi[0][1], 2048 + 32);
-            VITVS_TR(vlo[0][2], 64);   VITVS_TR(vhi[0][2], 2048 + 64); VITVS_TR(vlo[0][3], 96);   VITVS_TR(vhi[0][3], 2048 + 96);
-            VITVS_TR(vlo[1][0], 4096); VITVS_TR(vhi[1][0], 6144);      VITVS_TR(vlo[1][1], 4128); VITVS_TR(vhi[1][1], 6144 + 32);
-            VITVS_TR(vlo[1][2], 4160); VITVS_TR(vhi[1][2], 6144 + 64); VITVS_TR(vlo[1][3], 4192); VITVS_TR(vhi[1][3], 6144 + 96);
+            const lds_u8* vbase = (const lds_u8*)(ldsK + 64 * 128) + v_row * 128 + 8 * (li & 3);
+            const unsigned va0 = (unsigned)(size_t)vbase + 32u * (unsigned)((0 + dh) ^ v_sw);   // dim block 0
+            const unsigned va1 = (unsigned)(size_t)vbase + 32u * (unsigned)((2 + dh) ^ v_sw);   // dim block 1
+#define VITVS_TR(dst, va, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(OFF))
+            VITVS_TR(vf[0][0][0], va0, 0);    VITVS_TR(vf[0][0][1], va0, 1024);        VITVS_TR(vf[0][1][0], va1, 0);    VITVS_TR(vf[0][1][1], va1, 1024);
+            VITVS_TR(vf[1][0][0], va0, 2048); VITVS_TR(vf[1][0][1], va0, 2048 + 1024); VITVS_TR(vf[1][1][0], va1, 2048); VITVS_TR(vf[1][1][1], va1, 2048 + 1024);
+            VITVS_TR(vf[2][0][0], va0, 4096); VITVS_TR(vf[2][0][1], va0, 4096 + 1024); VITVS_TR(vf[2][1][0], va1, 4096); VITVS_TR(vf[2][1][1], va1, 4096 + 1024);
+            VITVS_TR(vf[3][0][0], va0, 6144); VITVS_TR(vf[3][0][1], va0, 6144 + 1024); VITVS_TR(vf[3][1][0], va1, 6144); VITVS_TR(vf[3][1][1], va1, 6144 + 1024);
 #undef VITVS_TR
         }
-        hx8 pf[2][2];
+        if (kb0 + 64 > N) {                              // keys beyond N: only the last tile has any (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float mloc = fmaxf(fmaxf(acc_s[j][0][0], acc_s[j][0][1]), fmaxf(acc_s[j][0][2], acc_s[j][0][3]));
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int t4 = 1; t4 < 4; ++t4)
-                mloc = fmaxf(mloc, fmaxf(fmaxf(acc_s[j][t4][0], acc_s[j][t4][1]), fmaxf(acc_s[j][t4][2], acc_s[j][t4][3])));
-            mloc = rows_max(mloc) * kScaleLog2e;
-            const float m_new = fmaxf(m_run[j], mloc);
-            const float neg_m = -m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(__builtin_fmaf(acc_s[j][t4][r], kScaleLog2e, neg_m));
-                    acc_s[j][t4][r] = p;
-                    psum += p;
-                }
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[j]) != 0ull) {
-                const float alpha = fast_exp2(m_run[j] - m_new);
-                l_run[j] *= alpha;
-#pragma unroll
-                for (int td = 0; td < 4; ++td) acc_o[j][td] *= alpha;
-                m_run[j] = m_new;
-            }
-            l_run[j] += psum;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[j][u][jj] = (HT)acc_s[j][2 * u + (jj >> 2)][jj & 3];
+                for (int i = 0; i < 16; ++i)
+                    if (kb0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) acc_s[kb][i] = -INFINITY;
         }
+        // softmax of the lane's 32 scores (one query); the other half of the query's keys sits in lane ^ 32
+        float mloc = max3(acc_s[0][0], acc_s[0][1], acc_s[0][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mloc = max3(mloc, acc_s[0][i], acc_s[0][i + 1]);
+        mloc = max3(mloc, acc_s[0][15], acc_s[1][0]);
+#pragma unroll
+        for (int i = 1; i < 15; i += 2) mloc = max3(mloc, acc_s[1][i], acc_s[1][i + 1]);
+        mloc = fmaxf(mloc, acc_s[1][15]);
+        mloc = fmaxf(mloc, lane_xor32(mloc)) * kScaleLog2e;
+        const float m_new = fmaxf(m_run, mloc);
+        const float neg_m = -m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = fast_exp2(__builtin_fmaf(acc_s[kb][i], kScaleLog2e, neg_m));
+                acc_s[kb][i] = p;
+                psum += p;
+            }
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
+        hx8 pf[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[st][j] = (HT)acc_s[st >> 1][8 * (st & 1) + j];
+        VITVS_STAMP(ts4);
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[0][2]), "+v"(vhi[0][2]),
-                       "+v"(vlo[0][3]), "+v"(vhi[0][3]), "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
-                       "+v"(vlo[1][2]), "+v"(vhi[1][2]), "+v"(vlo[1][3]), "+v"(vhi[1][3]));
+                     : "+v"(vf[0][0][0]), "+v"(vf[0][0][1]), "+v"(vf[0][1][0]), "+v"(vf[0][1][1]), "+v"(vf[1][0][0]), "+v"(vf[1][0][1]),
+                       "+v"(vf[1][1][0]), "+v"(vf[1][1][1]), "+v"(vf[2][0][0]), "+v"(vf[2][0][1]), "+v"(vf[2][1][0]), "+v"(vf[2][1][1]),
+                       "+v"(vf[3][0][0]), "+v"(vf[3][0][1]), "+v"(vf[3][1][0]), "+v"(vf[3][1][1]));
         __builtin_amdgcn_sched_barrier(0);
-        // O^T += V^T P^T for both query tiles; k-slot (g, jj) of step u  <->  key 32u + 16(jj>>2) + 4g + (jj&3)
+        // O^T[dim][query] += V^T P^T, 4 k-steps of 16 keys x 2 dim blocks
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int td = 0; td < 4; ++td) {
-                const s16x4 lo = vlo[u][td], hi = vhi[u][td];
+            for (int db = 0; db < 2; ++db) {
+                const s16x4 lo = vf[st][db][0], hi = vf[st][db][1];
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc_o[j][td] = mfma16(__builtin_bit_cast(hx8, v8), pf[j][u], acc_o[j][td]);
+                acc_o[db] = mfma32(__builtin_bit_cast(hx8, v8), pf[st], acc_o[db]);
             }
+#ifdef VITVS_PROBE
+        asm volatile("s_nop 0" ::"v"(acc_o[0][0]), "v"(acc_o[1][15]) : "memory");
+        VITVS_STAMP(ts5);
+        sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4;
+#endif
     }
+#ifdef VITVS_PROBE
+    if (lane == 0 && g_attn_probe) {
+        unsigned long long* dst = g_attn_probe + ((size_t)blockIdx.x * 4 + wave) * 8;
+        dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3]; dst[4] = sum[4];
+        dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = __builtin_amdgcn_s_memrealtime() - rt0; dst[7] = (unsigned long long)ntiles;
+    }
+#endif
+    // acc_o[db][i] = O[query r32][dim 32 db + (i & 3) + 8 (i >> 2) + 4 hh] * l
+    const float inv = 1.0f / (l_run + lane_xor32(l_run));
+    const int q = q0 + r32;
+    if (q < N) {
+        HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * hh;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float inv = 1.0f / rows_sum(l_run[j]);
-        const int q = q0 + 16 * j + qi;
-        if (q < N) {
-            HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * g;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int td = 0; td < 4; ++td) {
-                const hx4 o = {(HT)(acc_o[j][td][0] * inv), (HT)(acc_o[j][td][1] * inv), (HT)(acc_o[j][td][2] * inv),
-                               (HT)(acc_o[j][td][3] * inv)};
-                store_out<false>(dst + 16 * td, o);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const hx4 o = {(HT)(acc_o[db][4 * g4 + 0] * inv), (HT)(acc_o[db][4 * g4 + 1] * inv), (HT)(acc_o[db][4 * g4 + 2] * inv),
+                               (HT)(acc_o[db][4 * g4 + 3] * inv)};
+                store_out<false>(dst + 32 * db + 8 * g4, o);
             }
-        }
     }
 }
 
@@ -652,6 +734,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 make_float4(acc_o[td][0] * inv, acc_o[td][1] * inv, acc_o[td][2] * inv, acc_o[td][3] * inv);
     }
 }
+
+#ifdef VITVS_PROBE
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <typename HT>
 static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream) {
