@@ -118,7 +118,17 @@ def launch_ranks(args, argv, script=None) -> int:
 
 # ----------------------------------------------------------------------------------------------- work model
 def split_k(m, n, k, bk):
-    """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip."""
+    """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip (bk = 64 for the 16-bit precisions, 32 for fp32)."""
+    if bk == 64 and m >= 1024 and n % 128 == 0:
+        t128 = -(-m // 256) * (n // 128)
+        if t128 >= 96:
+            return 1
+        pick = 1
+        for c in (2, 3, 4):
+            if k % (c * 64) == 0 and k // c >= 8 * 64 and t128 * c <= 256:
+                pick = c
+        if pick > 1:
+            return pick
     tiles = -(-m // 64) * (n // 64)
     best = 1
     for c in (2, 3, 4, 6, 8):
@@ -489,16 +499,43 @@ def run_rank(args):
     fl = sum(work[c][0] * kernels[c]["launches_per_step"] for c in members) / launches
     by = sum(work[c][1] * kernels[c]["launches_per_step"] for c in members) / launches
 
-    def narrow_tile(m, n, kk):   # mirror of the tile choice for the N = D layers in csrc/gemm.hip
-        s_ = split_k(m, n, kk, 128 // es)
+    def big_tile(m, n, kk, s_):   # mirror of big_tile_width() in csrc/gemm_big.hip
+        if es == 4 or kk % (s_ * 64) or kk // s_ < 128:
+            return 0
+        ny_ = -(-m // 256)
+        if n % 256 == 0 and 120 <= ny_ * (n // 256) * s_ <= 256:
+            return 256
+        if n % 128 == 0 and ny_ * (n // 128) * s_ >= 96:
+            return 128
+        return 0
+
+    def linear_symbol(m, n, kk, s_, epi_small, epi_big):   # mirror of the tile choice in csrc/gemm.hip / gemm_big.hip
+        bn = big_tile(m, n, kk, s_)
+        if bn:
+            return f"linear_big_kernel<{prec_tag},256x{bn}>:{epi_big}"
         if s_ == 1 and n % 128 == 0 and -(-m // 128) * (n // 128) >= 256:
-            return "128,128,1"
-        tiles = -(-m // 64) * (n // 64) * s_
-        return "64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1"
-    symbol = {"linear_partial(proj+fc2)": f"linear_kernel<{prec_tag},{narrow_tile(2 * B * cfg.seq, cfg.dim, cfg.hidden)}>:EpiPartial",
-              "residual_ln": f"residual_ln_kernel<{prec_tag}>", "fc1": f"linear_kernel<{prec_tag},64,96,2>:EpiStore",
-              "qkv": f"linear_kernel<{prec_tag},64,64,2>:EpiStore",
-              "attention": "attention_f32_kernel" if prec_tag == "f32" else f"attention_16_kernel<{prec_tag}>"}.get(dom, dom)
+            return f"linear_kernel<{prec_tag},128,128,1>:{epi_small}"
+        if epi_small == "EpiPartial":
+            tiles = -(-m // 64) * (n // 64) * s_
+            return f"linear_kernel<{prec_tag}," + ("64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1") + ">:EpiPartial"
+        best, bn_ = -1, 64
+        for c in (128, 96, 64):
+            if n % c == 0 and -(-m // 64) * (n // c) <= 256 and -(-m // 64) * (n // c) > best:
+                best, bn_ = -(-m // 64) * (n // c), c
+        if best < 0:
+            bn_ = 128 if n % 128 == 0 else 64
+        kg = 2 if (-(-m // 64) * (n // bn_) <= 256 and kk // (128 // es) >= 4 and (kk // (128 // es)) % 2 == 0) else 1
+        return f"linear_kernel<{prec_tag},64,{bn_},{kg}>:EpiStore"
+    m_all = 2 * B * cfg.seq
+    bk_es = 128 // es
+    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es), "EpiPartial", "BigPartial"),
+              "residual_ln": f"residual_ln_kernel<{prec_tag}>",
+              "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, "EpiStore", "BigStore"),
+              "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, "EpiStore", "BigStore"),
+              "attention": "attention_f32_kernel" if prec_tag == "f32" else
+                           (f"attention_16_long_kernel<{prec_tag}>" if cfg.seq >= 512 else
+                            (f"attention_16_short_kernel<{prec_tag}>" if cfg.seq <= 256 and -(-cfg.seq // 16) * cfg.heads * 2 * B <= 640
+                             else f"attention_16_kernel<{prec_tag}>"))}.get(dom, dom)
     # HBM traffic (PMC) comes from separate rocprofv3 --pmc passes of this same command, never from this run: the line
     # says which committed file and which commit of the kernels it was measured on, and mixes it into no live ratio.
     traffic, traffic_source = None, None

@@ -151,7 +151,9 @@ def test_attention_asymmetric_values_catch_transposed_operands(lib):
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("M,D,K,use_ls,use_ln", [(394, 768, 768, False, True), (394, 768, 3072, True, True),
-                                                  (130, 384, 1536, False, False), (6274, 768, 768, False, True)])
+                                                  (130, 384, 1536, False, False), (6274, 768, 768, False, True),
+                                                  (3152, 768, 3072, False, True), (2740, 1024, 4096, True, True),
+                                                  (2740, 1024, 1024, False, True)])
 def test_split_k_pair(lib, name, prec, dtype, tol, M, D, K, use_ls, use_ln):
     """linear_partial + residual_ln == x + ls * (A W^T + bias), then LayerNorm (the proj / fc2 path of the forward)."""
     g = torch.Generator().manual_seed(M + D + K)

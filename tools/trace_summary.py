@@ -7,16 +7,8 @@ import re
 import sys
 
 
-def short(name):
-    name = re.sub(r"vitvs::", "", name)
-    m = re.match(r"_ZN5vitvs\d+(\w+?)I", name)
-    if m:
-        epi = re.search(r"(EpiStore|EpiPartial|EpiPatch|EpiResidual)", name)
-        kind = "bf16" if "DF16b" in name else "f32"
-        dims = re.search(r"Li(\d+)ELi(\d+)ELi(\d+)E", name)
-        extra = f"<{kind},{'x'.join(dims.groups())}>" if dims else f"<{kind}>"
-        return m.group(1) + extra + (":" + epi.group(1) if epi else "")
-    return name.split("(")[0][:40]
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from symbols import short  # noqa: E402
 
 
 def main():

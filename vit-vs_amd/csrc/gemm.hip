@@ -304,9 +304,22 @@ int launch_linear_residual(Precision p, const void* A, const void* W, const floa
 }
 
 int splitk_slices(Precision p, int M, int N, int K) {
+    const int bk = k_tile(p);
+    // Many rows, narrow layer (8 frame pairs or a 518² input through proj / fc2): the 256x128 tiles of gemm_big.hip fill
+    // well under half of the chip (78 tiles at 3152 x 768), so K is cut into the most slices that still fit one workgroup
+    // per CU and leave >= 8 k-tiles per slice (3152 x 768 x 3072: 35 us on the tiles below -> 3 slices of 234 tiles).
+    if (p != PREC_F32 && M >= 1024 && N % 128 == 0) {
+        const long t128 = (long)((M + 255) / 256) * (N / 128);
+        if (t128 >= 96) return 1;
+        int pick = 1;
+        for (int c : {2, 3, 4}) {
+            if (K % (c * 64) != 0 || K / c < 8 * 64) continue;
+            if (t128 * c <= 256) pick = c;
+        }
+        if (pick > 1) return pick;
+    }
     // The most K slices that still put at most one workgroup on every CU (each slice >= 4 k-tiles);
     // none if the tiles alone already cover the chip.
-    const int bk = k_tile(p);
     const long tiles = (long)((M + 63) / 64) * (N / 64);
     int best = 1;
     for (int c : {2, 3, 4, 6, 8}) {
