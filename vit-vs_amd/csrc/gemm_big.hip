@@ -84,13 +84,10 @@ template <typename T, class Tile, class Epi>
 __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                            typename Epi::Out* __restrict__ out, const float* __restrict__ bias,
                                                            int M, int N, int K, int flags, int slots) {
-    // flags: [31:24] k-tiles per split-K slice, [23:16] column tiles, [15:8] slices, [0] gelu.  PERSISTENT workgroups:
-    // a 1-D grid of `slots` (a multiple of 8, at most one per CU) workgroups; workgroup i runs on XCD i % 8 (its own
-    // L2); XCD x owns the x-th eighth of the (slice, row tile, column tile) list, column fastest — a few A row panels
-    // and the weight panels of one slice — and its slots / 8 workgroups walk that eighth with stride slots / 8.  A
-    // tile's output stores drain while the workgroup already requests the next tile's operands, and workgroups drift
-    // apart, so the chip's store bursts no longer coincide (one bulk-synchronous round per tile measured 9 us of fixed
-    // cost per round at 6274 x 2304: profiles/r02_notes.md).
+    // flags: [31:24] k-tiles per split-K slice, [23:16] column tiles, [15:8] slices, [0] gelu; slots: [15:0] workgroups in
+    // the grid (a multiple of 8, at most one per CU), [31:16] XCD map (below).  PERSISTENT workgroups: the slots / 8
+    // workgroups of an XCD walk that XCD's tile list with stride slots / 8; a tile's output stores drain while the
+    // workgroup already requests the next tile's operands.
     constexpr int MT = Tile::MT, NT = Tile::NT, WGN = Tile::WGN;
     constexpr int LA = Tile::LA, LB = Tile::LB, FULL = 2 * LA + 2 * LB;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -99,9 +96,27 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     const unsigned fl = (unsigned)flags;
     const int nk = (int)(fl >> 24), nx = (int)((fl >> 16) & 255), nz = (int)((fl >> 8) & 255);
     const int ny = (M + Tile::BM - 1) / Tile::BM;
-    const int tiles = nx * ny * nz, per = (tiles + 7) >> 3;
-    const int xcd = (int)(blockIdx.x & 7), stride = slots >> 3;
-    const int lin_end = min((xcd + 1) * per, tiles);
+    // Tile list of this XCD (workgroup i runs on XCD i % 8).  `xmap` = 0: the x-th eighth of the (slice, row tile, column
+    // tile) list, column fastest — balanced to one tile, used whenever every CU has at most one tile.  `xmap` = XR in
+    // {1, 2, 4, 8} (several tiles per CU): the XCDs form an XR x (8 / XR) grid over (row-slices, column tiles) and each owns
+    // one block, so that what its CUs stream concurrently is a few A panels and a few W panels that stay in its 4 MB L2
+    // (6274 x 3072 on 256x128 tiles: every XCD re-read all 4.7 MB of W on each of its three passes, 108 MB fetched for
+    // 14 MB of operands; as a 4 x 2 grid: 7 row panels + 12 column panels per XCD).
+    const int tiles = nx * ny * nz;
+    const int xcd = (int)(blockIdx.x & 7), local = (int)(blockIdx.x >> 3);
+    const int stride = (slots & 0xffff) >> 3, xmap = slots >> 16;
+    int blk_r0 = 0, blk_c0 = 0, blk_cols = nx, blk_tiles;
+    if (xmap == 0) {
+        const int per = (tiles + 7) >> 3;
+        blk_r0 = xcd * per;                                   // (used as a linear offset in this mode)
+        blk_tiles = min(per, tiles - xcd * per);
+    } else {
+        const int xc_n = 8 / xmap, xr_i = xcd / xc_n, xc_i = xcd - xr_i * xc_n, R = ny * nz;
+        blk_r0 = (R * xr_i) / xmap;
+        blk_c0 = (nx * xc_i) / xc_n;
+        blk_cols = (nx * (xc_i + 1)) / xc_n - blk_c0;
+        blk_tiles = ((R * (xr_i + 1)) / xmap - blk_r0) * blk_cols;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WGN, wc = wave - wr * WGN;     // waves 0 .. 3 and 4 .. 7 are the two staggered groups
@@ -109,9 +124,20 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
     bool first_tile = true;
-  for (int lin = xcd * per + (int)(blockIdx.x >> 3); lin < lin_end; lin += stride) {
-    const int tz = lin / (nx * ny), rem = lin - tz * nx * ny;
-    const int ty = rem / nx, tx = rem - ty * nx;
+  for (int it = local; it < blk_tiles; it += stride) {
+    int tz, ty, tx;
+    if (xmap == 0) {
+        const int lin = blk_r0 + it;
+        tz = lin / (nx * ny);
+        const int rem = lin - tz * nx * ny;
+        ty = rem / nx;
+        tx = rem - ty * nx;
+    } else {
+        const int rr = blk_r0 + it / blk_cols;
+        tx = blk_c0 + (it - (it / blk_cols) * blk_cols);
+        tz = rr / ny;
+        ty = rr - tz * ny;
+    }
     const int m0 = ty * Tile::BM, n0 = tx * Tile::BN, k0 = tz * nk * 64;
     if (!first_tile) {
         // every wave has read its epilogue image back (its stores are issued): the ring may be overwritten
@@ -336,8 +362,23 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
     if (N % Tile::BN || K % (splits * 64) || nk < 2 || nk > 255 || nx > 255 || splits > 255) return -2;
     const long tiles = (long)nx * ny * splits;
     const int slots = (int)std::min<long>(8 * ((tiles + 7) / 8), 256);       // one workgroup per CU at most
+    // XCD map (see the kernel): blocks of an XR x (8 / XR) XCD grid when CUs walk several tiles; among the grids whose
+    // largest block needs no more passes than the balanced 1-D split, the one with the fewest operand bytes per XCD
+    int xmap = 0;
+    if (tiles > 256) {
+        const long R = (long)ny * splits, wgs = slots / 8;
+        const long passes_1d = ((tiles + 7) / 8 + wgs - 1) / wgs;
+        double best = 1e30;
+        for (int xr : {1, 2, 4, 8}) {
+            const long xc = 8 / xr, rows = (R + xr - 1) / xr, cols = (nx + xc - 1) / xc;
+            if ((rows * cols + wgs - 1) / wgs > passes_1d) continue;
+            const double bytes = (double)rows * Tile::BM + (double)cols * Tile::BN * std::max<long>(1, (rows + ny - 1) / ny);
+            if (bytes < best) { best = bytes; xmap = xr; }
+        }
+    }
     launch(linear_big_kernel<T, Tile, Epi>, dim3((unsigned)slots), dim3(512), Tile::LDS_BYTES, stream, A, W, out, bias, M, N, K,
-           (int)(((unsigned)nk << 24) | ((unsigned)nx << 16) | ((unsigned)splits << 8) | (unsigned)(gelu & 1)), slots);
+           (int)(((unsigned)nk << 24) | ((unsigned)nx << 16) | ((unsigned)splits << 8) | (unsigned)(gelu & 1)),
+           (int)((unsigned)slots | ((unsigned)xmap << 16)));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
