@@ -746,6 +746,7 @@ static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H,
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
+    // (the 16-query kernel beyond 640 workgroups: 16 images x 197 tokens 16.2 us against 12.6 us on the 64-query kernel)
     if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32)) {
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,

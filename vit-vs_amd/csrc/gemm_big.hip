@@ -341,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
             for (int i = 0; i < BATCH; ++i) {
                 const int row = (b0 + i) * ROWS_PER_INST + lane_e / CHUNKS, chunk = lane_e & (CHUNKS - 1);
                 const int m = wm0 + pass * PASS_MT * 16 + row;
-                if (m < M) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0) + chunk * 16) = rowv[i];
+                // write-through (sc1): the rows leave for memory as they are stored instead of waiting, dirty in this XCD's
+                // L2, for the write-back at the kernel boundary (measured -3 ... -7 % on these launches: all of a tile's
+                // output is produced at its very end, so there is nothing for a write-back cache to merge)
+                if (m < M) store_out16<true>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0) + chunk * 16, rowv[i]);
             }
         }
         if (pass + 1 < MT / PASS_MT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
