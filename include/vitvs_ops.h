@@ -33,7 +33,9 @@ VITVS_API int vitvs_op_linear_residual(int32_t precision, const void* A, const v
 /* out[M][D] = LayerNorm(x[M][D]) * gamma + beta; x fp32, out in `precision`; D in {128,256,384,768,1024} */
 VITVS_API int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
                        int32_t D, float eps, void* stream);
-/* out[n_img*N][H*64] = softmax(q k^T / 8) v per (image, head); qkv [n_img*N][3*H*64] */
+/* out[n_img*N][H*64] = softmax(q k^T / 8) v per (image, head); qkv [n_img*N][3*H*64].  From 512 tokens on the keys of a query
+ * block may be split over several workgroups that merge through a per-DEVICE workspace this hook owns: calls for one device
+ * must be ordered on one stream (handles own their workspace and have no such restriction between handles). */
 VITVS_API int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
                        void* stream);
 

@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
     }
     if (sweep) return 0;
     // long-sequence attention: (images, tokens, heads)
-    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}};
+    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}};
     for (auto& a : att) {
         const int n_img = a[0], N = a[1], H = a[2], D = H * 64;
         void* qkv = rand_bf16((size_t)n_img * N * 3 * D, 1.0f, 9);
@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
         typedef int (*set_probe_t)(void*);
         set_probe_t set_probe = (set_probe_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_attn_probe");
         if (set_probe && N >= 512) {
-            const int wgs = 8 * ((((N + 127) / 128) * H * n_img + 7) / 8);
+            const int wgs = 4 * 8 * ((((N + 127) / 128) * H * n_img + 7) / 8);      // up to 4 key ranges per query block
             unsigned long long* buf;
             CHECK(hipMalloc((void**)&buf, (size_t)wgs * 4 * 8 * 8));
             CHECK(hipMemset(buf, 0, (size_t)wgs * 4 * 8 * 8));

@@ -78,6 +78,7 @@ struct vitvs_handle {
     // activations
     void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
     float *x = nullptr, *dn = nullptr, *sq = nullptr, *part = nullptr;  // part: split-K partial sums [8][M][D]
+    AttnWorkspace attn_ws;    // key-split states / tickets of the long-sequence attention, sized for every image count <= n_img_max
     size_t dn_elems = 0;
     unsigned long long *row_best = nullptr, *col_best = nullptr;
     size_t best_elems = 0;
@@ -270,7 +271,7 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_QKV, st);
             rc = launch_linear(h->prec, cx[k].xn, b.qkvw, b.qkvb, cx[k].qkv, cx[k].M, 3 * D, D, 0, st); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_ATTENTION, st);
-            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st); }
+            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st, &h->attn_ws); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PROJ, st);
             rc = launch_linear_partial(h->prec, cx[k].attn, b.projw, cx[k].part, cx[k].M, D, D,
                                        splitk_slices(h->prec, cx[k].M, D, D), st); }
@@ -427,6 +428,15 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 #undef ALLOC_BYTES
     if (!rc) rc = dev_alloc(h, &h->x, M * D);
     if (!rc) rc = dev_alloc(h, &h->part, (size_t)8 * M * D);   // at most 8 split-K slices (splitk_slices)
+    {   // the key-split plan depends on the image count of a call: size for the largest need over 1 .. n_img_max
+        size_t f = 0, t = 0;
+        for (int n = 1; n <= h->n_img_max; ++n) {
+            f = std::max(f, attention_workspace_floats(n, h->N, cfg->heads));
+            t = std::max(t, attention_ticket_count(n, h->N, cfg->heads));
+        }
+        if (!rc && f) rc = dev_alloc(h, &h->attn_ws.state, f);
+        if (!rc && t) rc = dev_alloc(h, &h->attn_ws.tickets, t);   // dev_alloc zeroes: the tickets start at 0
+    }
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);

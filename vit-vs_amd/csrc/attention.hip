@@ -21,6 +21,8 @@
 // measured 1 % slower end to end than this streaming form and was removed: profiles/r01_notes.md.)
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -248,9 +250,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// Key split (splits = 2 or 4): 600 query blocks on 768 workgroup slots leave some CUs with three workgroups and most with two
+// (the median wave is done at 76 of 101 us), and 352 blocks (1370 tokens) leave most CUs with one.  The key tiles of a query
+// block are therefore cut into `splits` contiguous ranges, one workgroup each; every workgroup leaves its un-normalised state
+// (O, running maximum, running sum) in `ws`, draws a ticket for its query block, and the one that draws the last ticket merges
+// the states in range order (fixed order: bit-reproducible) and writes the output.  The hand-off is the write-through form of
+// the CDNA4 guide's recipe (state stored with 16-byte sc1 stores, every wave drains them, workgroup barrier, one lane draws
+// the ticket with a relaxed agent-scope add; the last arriver: agent acquire fence, barrier, plain loads) and does not depend
+// on placement; a release fence per workgroup instead (an L2 write-back each, 1200 of them per launch) made the launch 13 %
+// SLOWER than not splitting at all.  The ticket is reset by the last arriver: the array only has to be zero before the
+// first launch.
+constexpr int kAttnStateFloats = 9 * 64 * 4;                // per wave: 8 x 16 bytes of accumulators + (maximum, sum), lane-major
+
 template <typename HT>
 __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
-                                                                   int D, int n_img) {
+                                                                   int D, int n_img, int splits, float* __restrict__ ws,
+                                                                   int* __restrict__ tickets) {
     typedef typename Vec16<HT>::x8 hx8;
     typedef typename Vec16<HT>::x4 hx4;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -261,9 +276,10 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     constexpr int STAGE = 2 * 64 * 128;                      // K tile then V tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
-    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, per = (items + 7) >> 3;
-    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (item >= items) return;
+    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, units = items * splits, per = (units + 7) >> 3;
+    const int unit = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (unit >= units) return;
+    const int item = unit / splits, part = unit - item * splits;
     const int pair = item / nqb;
     const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 128 + 32 * wave;
     const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
@@ -285,13 +301,20 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7)) + (unsigned)krow[c] * row_bytes;
         voff[c] = v_off + 16u * (unsigned)((lane & 7) ^ (((krow[c] >> 1) & 1) << 2)) + (unsigned)krow[c] * row_bytes;
     }
-    const int ntiles = (N + 63) >> 6;
-    // source offsets advance by 64 rows per tile (one add per copy); only the last tile can reach past row N - 1 and
-    // takes the clamped form
+    // this workgroup's key tiles: [t_begin, t_begin + ntiles) of the ntiles_all tiles of the sequence
+    const int ntiles_all = (N + 63) >> 6, chunk = (ntiles_all + splits - 1) / splits;
+    const int t_begin = part * chunk, ntiles = min(chunk, ntiles_all - t_begin);
+    // source offsets advance by 64 rows per tile (one add per copy); only the sequence's last tile can reach past row
+    // N - 1 and takes the clamped form
     const unsigned tile_bytes = 64u * row_bytes;
-    auto issue = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        koff[c] += (unsigned)t_begin * tile_bytes;
+        voff[c] += (unsigned)t_begin * tile_bytes;
+    }
+    auto issue = [&](int t) {                                  // t: tile index inside this workgroup's range
         unsigned char* dst = smem + (t % 3) * STAGE + (16 * wave) * 128;
-        if (t + 1 < ntiles) {
+        if (t_begin + t + 1 < ntiles_all) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + koff[c]), (lds_ptr)(dst + c * 1024), 16, 0, 0);
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         } else {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const unsigned back = __umul24((unsigned)max(64 * t + krow[c] - (N - 1), 0), row_bytes);   // rows past the end -> row N - 1
+                const unsigned back = __umul24((unsigned)max(64 * (t_begin + t) + krow[c] - (N - 1), 0), row_bytes);   // rows past the end -> row N - 1
                 __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] - back)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] - back)), (lds_ptr)(dst + 64 * 128 + c * 1024), 16, 0, 0);
             }
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         VITVS_STAMP(ts2);
         if (t + 2 < ntiles) issue(t + 2);
         const unsigned char* ldsK = smem + (t % 3) * STAGE;
-        const int kb0 = t * 64;
+        const int kb0 = (t_begin + t) * 64;
         // scores: acc_s[kb][i] = S[key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 hh][query r32]
         f32x16 acc_s[2];
         {
@@ -460,8 +483,74 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = __builtin_amdgcn_s_memrealtime() - rt0; dst[7] = (unsigned long long)ntiles;
     }
 #endif
+    l_run += lane_xor32(l_run);                                // both lane halves hold the query's whole sum
+    if (splits > 1) {
+        // leave this range's state: ws[unit][wave][group 0 .. 8][lane] x 16 bytes, written through (sc1)
+        float* mine = ws + ((size_t)unit * 4 + wave) * kAttnStateFloats + 4 * lane;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                store_out<true>(mine + (4 * db + g4) * 256,
+                                f32x4{acc_o[db][4 * g4], acc_o[db][4 * g4 + 1], acc_o[db][4 * g4 + 2], acc_o[db][4 * g4 + 3]});
+        store_out<true>(mine + 8 * 256, f32x4{m_run, l_run, 0.f, 0.f});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
+        __syncthreads();                                       // ... before the workgroup's one ticket
+        int* flag = reinterpret_cast<int*>(smem);              // (the ring is dead: every wave is past its last tile)
+        if (tid == 0) {
+            const int drawn = __hip_atomic_fetch_add(tickets + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (drawn == splits - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *flag = drawn;
+        }
+        __syncthreads();
+        if (*flag != splits - 1) return;                       // not the last arriver of this query block
+        // merge the ranges' states in range order; this workgroup's own state comes from its registers
+        const float* st0 = ws + ((size_t)(item * splits) * 4 + wave) * kAttnStateFloats + 4 * lane;
+        float m_tot = -INFINITY;
+        for (int p2 = 0; p2 < splits; ++p2) {
+            const float mp = (p2 == part) ? m_run : st0[(size_t)p2 * 4 * kAttnStateFloats + 8 * 256];
+            m_tot = fmaxf(m_tot, mp);
+        }
+        float l_tot = 0.f;
+        f32x16 o_tot[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_tot[db][i] = 0.f;
+        for (int p2 = 0; p2 < splits; ++p2) {
+            const float* st = st0 + (size_t)p2 * 4 * kAttnStateFloats;
+            const bool own = p2 == part;                       // wave-uniform
+            float mp = m_run, lp = l_run;
+            f32x4 og[8];
+            if (!own) {
+                const f32x4 ml = *reinterpret_cast<const f32x4*>(st + 8 * 256);
+                mp = ml[0];
+                lp = ml[1];
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) og[g8] = *reinterpret_cast<const f32x4*>(st + g8 * 256);
+            } else {
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8)
+                    og[g8] = f32x4{acc_o[g8 >> 2][4 * (g8 & 3)], acc_o[g8 >> 2][4 * (g8 & 3) + 1], acc_o[g8 >> 2][4 * (g8 & 3) + 2],
+                                   acc_o[g8 >> 2][4 * (g8 & 3) + 3]};
+            }
+            const float wgt = fast_exp2(mp - m_tot);           // an empty range (m = -inf) gets weight 0
+            l_tot += lp * wgt;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o_tot[g8 >> 2][4 * (g8 & 3) + r] += og[g8][r] * wgt;
+        }
+        l_run = l_tot;
+        acc_o[0] = o_tot[0];
+        acc_o[1] = o_tot[1];
+    }
     // acc_o[db][i] = O[query r32][dim 32 db + (i & 3) + 8 (i >> 2) + 4 hh] * l
-    const float inv = 1.0f / (l_run + lane_xor32(l_run));
+    const float inv = 1.0f / l_run;
     const int q = q0 + r32;
     if (q < N) {
         HT* dst = out + ((size_t)img * N + q) * D + h * 64 + 4 * hh;
@@ -741,8 +830,65 @@ extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe
 }
 #endif
 
+// How many key ranges per query block for the long-sequence kernel: the fewest of {1, 2, 4} that minimises the number of
+// half / quarter blocks the busiest CU gets, relative to their size (3 workgroups fit a CU; below ~2 per CU a CU is
+// latency-bound, so more, smaller units win ties); every range keeps at least 4 key tiles.
+int attention_splits(int n_img, int N, int H) {
+    if (N < 512) return 1;
+#ifdef VITVS_ATTN_FORCE_SPLITS                                  // experiments only (tools/): never defined in the product build
+    return ((N + 63) / 64) / VITVS_ATTN_FORCE_SPLITS >= 2 ? VITVS_ATTN_FORCE_SPLITS : 1;
+#endif
+    const long items = (long)((N + 127) / 128) * H * n_img;
+    const int ntiles = (N + 63) / 64;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp : {1, 2, 4}) {
+        if (sp > 1 && ntiles / sp < 4) break;
+        const long units = items * sp;
+        const double cost = (double)((units + 255) / 256) / sp;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }   // ties: the fewer ranges
+    }
+    return best;
+}
+
+size_t attention_workspace_floats(int n_img, int N, int H) {
+    const int sp = attention_splits(n_img, N, H);
+    return sp > 1 ? (size_t)((N + 127) / 128) * H * n_img * sp * 4 * kAttnStateFloats : 0;
+}
+size_t attention_ticket_count(int n_img, int N, int H) {
+    return attention_splits(n_img, N, H) > 1 ? (size_t)((N + 127) / 128) * H * n_img : 0;
+}
+
+// The pointer-only operator hook (vitvs_op_attention) has no handle to own the key-split workspace: one per device, grown on
+// demand (synchronising; handles pre-size their own at creation so that nothing is allocated on the call path).
+static AttnWorkspace* shared_attention_workspace(size_t floats, size_t tickets) {
+    static std::mutex mu;
+    static AttnWorkspace per_device[64];
+    static size_t cap_f[64], cap_t[64];
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64) return nullptr;
+    AttnWorkspace& w = per_device[dev];
+    if (floats > cap_f[dev]) {
+        (void)hipDeviceSynchronize();
+        if (w.state) (void)hipFree(w.state);
+        if (hipMalloc((void**)&w.state, floats * sizeof(float)) != hipSuccess) { w.state = nullptr; cap_f[dev] = 0; return nullptr; }
+        cap_f[dev] = floats;
+    }
+    if (tickets > cap_t[dev]) {
+        (void)hipDeviceSynchronize();
+        if (w.tickets) (void)hipFree(w.tickets);
+        if (hipMalloc((void**)&w.tickets, tickets * sizeof(int)) != hipSuccess || hipMemset(w.tickets, 0, tickets * sizeof(int)) != hipSuccess) {
+            w.tickets = nullptr; cap_t[dev] = 0; return nullptr;
+        }
+        (void)hipDeviceSynchronize();          // the zeros are in place before any stream's launch draws a ticket
+        cap_t[dev] = tickets;
+    }
+    return &w;
+}
+
 template <typename HT>
-static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream) {
+static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream, const AttnWorkspace* ws) {
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
@@ -752,27 +898,37 @@ static void launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H,
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
                out, N, D, n_img);
     } else if (N >= 512 && (long)n_img * N * 6 * D < (1l << 32)) {
-        const int items = ((N + 127) / 128) * H * n_img;
-        launch(attention_16_long_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 3 * 2 * 64 * 128, stream, qkv, out, N, D, n_img);
+        const int sp = attention_splits(n_img, N, H);
+        const int units = ((N + 127) / 128) * H * n_img * sp;
+        if (sp > 1) {
+            if (!ws) ws = shared_attention_workspace(attention_workspace_floats(n_img, N, H), attention_ticket_count(n_img, N, H));
+            if (!ws || !ws->state || !ws->tickets) return -3;
+        }
+        launch(attention_16_long_kernel<HT>, dim3(8 * ((units + 7) / 8)), dim3(256), 3 * 2 * 64 * 128, stream, qkv, out, N, D, n_img,
+               sp, sp > 1 ? ws->state : nullptr, sp > 1 ? ws->tickets : nullptr);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
     } else {
         launch((attention_16_kernel<HT, 1>), grid, dim3(256), 2 * 64 * 128, stream, qkv, out, N, D);
     }
+    return 0;
 }
 
-int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream) {
+int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream,
+                     const AttnWorkspace* ws) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
     const int D = H * 64;
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
+    int rc = 0;
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (p == PREC_F16) {
-        launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream);
+        rc = launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, ws);
     } else {
-        launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream);
+        rc = launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream, ws);
     }
+    if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

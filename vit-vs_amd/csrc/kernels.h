@@ -136,7 +136,18 @@ int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStr
 
 // ---- attention.hip -------------------------------------------------------------------------
 // out[img*N + q][h*64 + d] = softmax_k(q.k * 64^-0.5) v ; qkv [n_img*N][3*D] in precision p.
-int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream);
+// Long sequences (>= 512 tokens) may cut the keys of a query block into ranges merged inside the launch; that needs a
+// workspace: `state` (attention_workspace_floats floats) and `tickets` (attention_ticket_count ints, ZERO before the first
+// launch; every launch leaves them zero).  ws = nullptr: a per-device workspace shared by all callers without one (the
+// operator hook), grown on demand.
+struct AttnWorkspace {
+    float* state = nullptr;
+    int* tickets = nullptr;
+};
+size_t attention_workspace_floats(int n_img, int N, int H);
+size_t attention_ticket_count(int n_img, int N, int H);
+int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream,
+                     const AttnWorkspace* ws = nullptr);
 
 // ---- correspond.hip ------------------------------------------------------------------------
 // For pair b: S = dn[a_img(b)] . dn[b_img(b)]^T (T x T, fp32); row_best[b][i] / col_best[b][j] receive
