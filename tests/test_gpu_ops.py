@@ -114,7 +114,8 @@ def _attention_ref(qkv, n_img, N, H):
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("n_img,N,H,scale", [(2, 197, 6, 1.0), (1, 64, 2, 1.0), (1, 70, 1, 3.0), (2, 257, 2, 2.0),
                                              (1, 1370, 2, 1.0), (3, 5, 1, 1.0), (2, 530, 3, 2.0), (1, 700, 1, 4.0),
-                                             (1, 3137, 1, 1.0), (9, 197, 12, 1.0)])
+                                             (1, 3137, 1, 1.0), (9, 197, 12, 1.0), (16, 197, 12, 1.0), (24, 130, 6, 2.0),
+                                             (48, 128, 4, 1.0), (7, 128, 8, 1.0), (16, 485, 6, 1.0)])
 def test_attention(lib, name, prec, dtype, tol, n_img, N, H, scale):
     g = torch.Generator().manual_seed(N * 3 + H)
     D = H * 64

@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
     }
     if (sweep) return 0;
     // long-sequence attention: (images, tokens, heads)
-    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}};
+    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
     for (auto& a : att) {
         const int n_img = a[0], N = a[1], H = a[2], D = H * 64;
         void* qkv = rand_bf16((size_t)n_img * N * 3 * D, 1.0f, 9);

@@ -842,10 +842,12 @@ int attention_splits(int n_img, int N, int H) {
     const int ntiles = (N + 63) / 64;
     int best = 1;
     double best_cost = 1e30;
+    // a range costs its tiles plus ~1.5 tiles for leaving / merging its state (measured: two ranges with nothing to balance cost
+    // +5 % at 50 tiles, +14..27 % at 13 tiles); the busiest CU walks ceil(units / 256) of them
     for (int sp : {1, 2, 4}) {
         if (sp > 1 && ntiles / sp < 4) break;
         const long units = items * sp;
-        const double cost = (double)((units + 255) / 256) / sp;
+        const double cost = (double)((units + 255) / 256) * ((double)ntiles / sp + (sp > 1 ? 1.5 : 0.0));
         if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }   // ties: the fewer ranges
     }
     return best;
@@ -897,7 +899,10 @@ static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, 
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
                out, N, D, n_img);
-    } else if (N >= 512 && (long)n_img * N * 6 * D < (1l << 32)) {
+    } else if ((N >= 512 || (N >= 128 && (long)nt * H * n_img >= 384)) && (long)n_img * N * 6 * D < (1l << 32)) {
+        // 128 queries per workgroup: from 512 tokens on, and for shorter sequences once the 64-query kernel would put more
+        // than ~1.5 workgroups on every CU (each re-reads its head's K / V): 16 x 197 x 12 heads 12.6 -> 10.7 us,
+        // 16 x 485 x 6 heads 20.1 -> 16.9 us; equal at 4 x 197 and 8 x 197
         const int sp = attention_splits(n_img, N, H);
         const int units = ((N + 127) / 128) * H * n_img * sp;
         if (sp > 1) {
