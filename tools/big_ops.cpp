@@ -73,7 +73,9 @@ int main(int argc, char** argv) {
     };
     const int nsets = 4;
     printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, classic, 256x256, 256x128");
-    const bool attn_only = argc > 1 && !strcmp(argv[1], "attn");
+    // "occ": attention only, on a probe build of the library, with the workgroups per CU limited through their LDS size
+    const bool occ = argc > 1 && !strcmp(argv[1], "occ");
+    const bool attn_only = occ || (argc > 1 && !strcmp(argv[1], "attn"));
     std::vector<Shape> todo;
     if (attn_only) todo.clear();
     else if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
@@ -106,8 +108,15 @@ int main(int argc, char** argv) {
     if (sweep) return 0;
     // long-sequence attention: (images, tokens, heads)
     const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
+    typedef int (*set_lds_t)(int);
+    set_lds_t set_lds = (set_lds_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_attn_lds");
+    if (occ && !set_lds) { printf("occ needs a probe build of the library\n"); return 1; }
+    for (int lds_kb : {48, 64, 100}) {
+    if (!occ && lds_kb != 48) break;
+    if (occ) { set_lds(lds_kb * 1024); printf("== %d KB of LDS per workgroup: %d workgroup(s) of 4 waves per CU\n", lds_kb, 160 / lds_kb); }
     for (auto& a : att) {
         const int n_img = a[0], N = a[1], H = a[2], D = H * 64;
+        if (occ && N < 1024) continue;
         void* qkv = rand_bf16((size_t)n_img * N * 3 * D, 1.0f, 9);
         void* out;
         CHECK(hipMalloc(&out, (size_t)n_img * N * D * 2));
@@ -131,12 +140,14 @@ int main(int argc, char** argv) {
             for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * 8 + 7]) for (int k = 0; k < 8; ++k) col[k].push_back((double)hbuf[(size_t)w * 8 + k]);
             auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             const double nt = med(col[7]);
-            printf("  probe (median over %zu waves, cycles per tile): wait-dma %.0f  barrier %.0f  issue+K-reads+QK %.0f  softmax %.0f  tr-wait+PV %.0f | total %.0f cycles in %.1f us -> %.2f GHz\n",
-                   col[0].size(), med(col[0]) / nt, med(col[1]) / nt, med(col[2]) / nt, med(col[3]) / nt, med(col[4]) / nt, med(col[5]), med(col[6]) / 100.0,
+            auto mean = [](const std::vector<double>& v) { double a = 0; for (double x : v) a += x; return v.empty() ? 0.0 : a / v.size(); };
+            printf("  probe (mean over %zu waves, cycles per tile): wait-dma %.0f  barrier %.0f  copy-issue+K-reads+scores %.0f  softmax %.0f  V-wait+PV %.0f | total %.0f cycles in %.1f us -> %.2f GHz\n",
+                   col[0].size(), mean(col[0]) / nt, mean(col[1]) / nt, mean(col[2]) / nt, mean(col[3]) / nt, mean(col[4]) / nt, med(col[5]), med(col[6]) / 100.0,
                    med(col[5]) / (med(col[6]) * 10.0));
             CHECK(hipFree(buf));
         }
         CHECK(hipFree(qkv)); CHECK(hipFree(out));
+    }
     }
     return 0;
 }

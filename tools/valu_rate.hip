@@ -109,6 +109,73 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long lo
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// Two roles in one workgroup of 8 waves (waves w and w + 4 share a SIMD): waves 0-3 issue only MFMAs, waves 4-7 only vector
+// instructions.  which: 1 = MFMA waves only, 2 = vector waves only, 3 = both.  Do the two streams run beside each other?
+template <int VOP>
+__global__ __launch_bounds__(512) void role_kernel(float* out, unsigned long long* cycles, float seed, int which) {
+    const int wave = threadIdx.x >> 6;
+    const bool mfma_role = wave < 4;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = seed * (threadIdx.x + i);
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 1.f; }
+    bf16x8 fa, fb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = (short)(threadIdx.x + i); fb[i] = (short)(threadIdx.x * 3 + i); }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    if (mfma_role) {
+        if (which & 1)
+            for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc2, 0, 0, 0);
+                }
+            }
+    } else if (which & 2) {
+        for (int it = 0; it < 4 * kIters; ++it) {
+            if constexpr (VOP == 0) {
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(seed));
+                REP16(OP)
+#undef OP
+            } else {
+#define OP(i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+                REP16(OP)
+#undef OP
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc2[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int VOP>
+static void measure_roles(const char* name, float* out, unsigned long long* cyc) {
+    printf("%-44s", name);
+    for (int which = 1; which <= 3; ++which) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(role_kernel<VOP>, dim3(256), dim3(512), 0, 0, out, cyc, 1e-3f, which);
+            CHECK(hipGetLastError());
+            CHECK(hipDeviceSynchronize());
+        }
+        unsigned long long h[256 * 8];
+        CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
+        double m = 0, v = 0;
+        for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? m : v) += (double)h[b * 8 + w];
+        m /= 256 * 4; v /= 256 * 4;
+        printf("  %s: mfma %7.2f /instr  vector %6.2f /instr", which == 1 ? "MFMA waves alone" : which == 2 ? "vector waves alone" : "both",
+               m / (16.0 * kIters), v / (64.0 * kIters));
+    }
+    printf("\n");
+}
+
 template <int MODE>
 static void measure(const char* name, int instr_per_iter, float* out, unsigned long long* cyc) {
     printf("%-44s", name);
@@ -149,5 +216,7 @@ int main() {
     measure<FMA_MFMA>("mfma 32x32x16 + 4 v_fma_f32 (per group)", 16, out, cyc);
     measure<MFMA_IND>("mfma 32x32x16, two accumulators", 16, out, cyc);
     measure<EXP_MFMA_IND>("mfma two accumulators + 2 v_exp_f32 each", 16, out, cyc);
+    measure_roles<0>("roles: 16 mfma 32x32x16 | 64 v_fma_f32", out, cyc);
+    measure_roles<1>("roles: 16 mfma 32x32x16 | 64 v_exp_f32", out, cyc);
     return 0;
 }

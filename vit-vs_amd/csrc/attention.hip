@@ -828,6 +828,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe(void* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
+// probe builds only: dynamic LDS per workgroup of the long kernel, to limit how many share a CU (48 KB: 3, 64 KB: 2, 100 KB: 1)
+static int g_attn_lds_bytes = 3 * 2 * 64 * 128;
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_lds(int bytes) {
+    g_attn_lds_bytes = bytes < 3 * 2 * 64 * 128 ? 3 * 2 * 64 * 128 : bytes;
+    return 0;
+}
 #endif
 
 // How many key ranges per query block for the long-sequence kernel: the fewest of {1, 2, 4} that minimises the number of
@@ -909,7 +915,15 @@ static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, 
             if (!ws) ws = shared_attention_workspace(attention_workspace_floats(n_img, N, H), attention_ticket_count(n_img, N, H));
             if (!ws || !ws->state || !ws->tickets) return -3;
         }
-        launch(attention_16_long_kernel<HT>, dim3(8 * ((units + 7) / 8)), dim3(256), 3 * 2 * 64 * 128, stream, qkv, out, N, D, n_img,
+        int lds = 3 * 2 * 64 * 128;
+#ifdef VITVS_PROBE
+        lds = g_attn_lds_bytes;
+        if (lds > 64 * 1024) {
+            static std::atomic<unsigned long long> raised{0};
+            if (raise_lds_limit((const void*)attention_16_long_kernel<HT>, 160 * 1024, raised)) return -3;
+        }
+#endif
+        launch(attention_16_long_kernel<HT>, dim3(8 * ((units + 7) / 8)), dim3(256), lds, stream, qkv, out, N, D, n_img,
                sp, sp > 1 ? ws->state : nullptr, sp > 1 ? ws->tickets : nullptr);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
