@@ -71,6 +71,16 @@ int main(int argc, char** argv) {
         {"1500x2304 K=128  ", 1500, 2304, 128, 0, 0},  {"1500x2304 K=768  ", 1500, 2304, 768, 0, 0},
         {"1500x2304 K=3072 ", 1500, 2304, 3072, 0, 0},
     };
+    // "slices": the narrow layers at 3152 / 2740 rows with 1..4 K slices (the forward adds ~1.8 us of residual_ln per extra slice)
+    const bool slices_mode = argc > 1 && !strcmp(argv[1], "slices");
+    const Shape slice_shapes[] = {
+        {"3152 proj 1 slice ", 3152, 768, 768, 0, 1},  {"3152 proj 2 slices", 3152, 768, 768, 0, 2},  {"3152 proj 3 slices", 3152, 768, 768, 0, 3},
+        {"3152 fc2  2 slices", 3152, 768, 3072, 0, 2}, {"3152 fc2  3 slices", 3152, 768, 3072, 0, 3}, {"3152 fc2  4 slices", 3152, 768, 3072, 0, 4},
+        {"2740 proj 1 slice ", 2740, 1024, 1024, 0, 1}, {"2740 proj 2 slices", 2740, 1024, 1024, 0, 2}, {"2740 proj 4 slices", 2740, 1024, 1024, 0, 4},
+        {"2740 fc2  2 slices", 2740, 1024, 4096, 0, 2}, {"2740 fc2  4 slices", 2740, 1024, 4096, 0, 4},
+        {"1576 proj 1 slice ", 1576, 768, 768, 0, 1},  {"1576 proj 2 slices", 1576, 768, 768, 0, 2},  {"1576 proj 3 slices", 1576, 768, 768, 0, 3},
+        {"1576 fc2  3 slices", 1576, 768, 3072, 0, 3}, {"1576 fc2  4 slices", 1576, 768, 3072, 0, 4}, {"1576 fc2  6 slices", 1576, 768, 3072, 0, 6},
+    };
     const int nsets = 4;
     printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, classic, 256x256, 256x128");
     // "occ": attention only, on a probe build of the library, with the workgroups per CU limited through their LDS size
@@ -79,6 +89,7 @@ int main(int argc, char** argv) {
     std::vector<Shape> todo;
     if (attn_only) todo.clear();
     else if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
+    else if (slices_mode) todo.assign(std::begin(slice_shapes), std::end(slice_shapes));
     else todo.assign(std::begin(shapes), std::end(shapes));
     for (const Shape& s : todo) {
         void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
@@ -105,7 +116,7 @@ int main(int argc, char** argv) {
         CHECK(hipFree(A)); CHECK(hipFree(out)); CHECK(hipFree(bias));
         for (int i = 0; i < nsets; ++i) CHECK(hipFree(Wt[i]));
     }
-    if (sweep) return 0;
+    if (sweep || slices_mode) return 0;
     // long-sequence attention: (images, tokens, heads)
     const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
     typedef int (*set_lds_t)(int);
