@@ -363,6 +363,38 @@ def test_16bit_modes_over_8_accepted_pairs(precision):
     assert checked >= 1
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("binned", [False, True])
+def test_many_token_gram_of_the_16bit_modes_equals_an_exact_gram_of_the_same_descriptors(precision, binned):
+    """From 1024 tokens on the 16-bit modes take the Gram on the f16 matrix cores from a hi / lo split of the descriptors
+    (correspond.hip).  Its arg-max tables must be those of an fp64 Gram of the SAME device descriptors, except across ties
+    below 1e-6; two pairs against one shared goal frame exercise both row layouts of the split."""
+    cfg = _tiny_cfg(False, img=512)  # 32 x 32 = 1024 tokens
+    sd = weights.synthetic_state_dict(cfg, 5)
+    params = config.ServoParams(dino_input_size=512, use_feature_binning=binned)
+    eng = _engine(cfg, params, precision=precision, max_pairs=2, binned=binned).load_state_dict(sd)
+    des, cur0 = synth.frame_pair(512, 20250801)
+    _, cur1 = synth.frame_pair(512, 20250802)
+    cur = np.stack([cur0, cur1])
+    depth = np.stack([synth.depth_pattern()] * 2)
+    order = np.stack([np.random.default_rng(7 + b).permutation(cfg.tokens).astype(np.int32) for b in range(2)])
+    v, st = eng.compute_velocity(cur, des[None], depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
+                                 des_shared=True)
+    det = eng.last_details(2)
+    assert np.all(np.isfinite(v.cpu().numpy()))
+    d = eng.extract_descriptors(np.concatenate([des[None], cur])).double().cpu()[:, 0]
+    dn = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    for b in range(2):
+        S = (dn[0] @ dn[1 + b].T).numpy()
+        for got, want_S in ((det["nn_1"][b], S), (det["nn_2"][b], S.T)):
+            best = want_S.max(1)
+            chosen = want_S[np.arange(cfg.tokens), got.astype(np.int64)]
+            assert float((best - chosen).max()) <= 1e-6, "an arg-max of the f16 Gram is not a maximum of the exact Gram"
+            exact = want_S.argmax(1)
+            assert float((got == exact).mean()) >= 0.995
+        np.testing.assert_allclose(det["sim_1"][b], S.max(1), rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("key", ["vitl14_518"])
 def test_forward_tokens_fp16_large_config(key):
     """DINOv2 ViT-L/14 518² in fp16 (configs[4]): tokens against the fp32 oracle, LayerScale model, resampled grid."""

@@ -78,6 +78,7 @@ struct vitvs_handle {
     // activations
     void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
     float *x = nullptr, *dn = nullptr, *sq = nullptr, *part = nullptr;  // part: split-K partial sums [8][M][D]
+    unsigned short* dh = nullptr;   // fp16 hi / lo split of dn for the many-token Gram of the 16-bit modes (null: fp32 Gram)
     AttnWorkspace attn_ws;    // key-split states / tickets of the long-sequence attention, sized for every image count <= n_img_max
     size_t dn_elems = 0;
     unsigned long long *row_best = nullptr, *col_best = nullptr;
@@ -439,6 +440,10 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     }
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
+    // 16-bit modes, >= 1024 tokens: the Gram runs on the f16 matrix cores from a hi / lo split of the descriptors (correspond.hip)
+    if (!rc && h->prec != PREC_F32 && h->T >= 1024 && h->Dp % 64 == 0 &&
+        gram_split_elems(h->n_img_max, h->T, h->Dp) * 2 < (1ull << 32))
+        rc = dev_alloc(h, &h->dh, gram_split_elems(h->n_img_max, h->T, h->Dp));
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
     h->best_elems = (size_t)cfg->max_pairs * h->T;
     if (!rc) rc = dev_alloc(h, &h->row_best, h->best_elems);
@@ -695,8 +700,13 @@ static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) 
                                 h->row_best, h->col_best, u.n_pairs * h->T, st);
         if (rc) return set_err(h, rc, "descriptor launch failed");
     }
+    if (h->dh) {
+        rc = launch_split_desc(h->dn, h->dh, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, st);
+        if (rc) return set_err(h, rc, "descriptor split launch failed");
+    }
     { Span sp(h, KC_GRAM, st);
-      rc = launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
+      rc = h->dh ? launch_gram_argmax_split(h->dh, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st)
+                 : launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");
     return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.num_pairs, u.selection, u.n_selected, u.v_c,
                      u.status, st);

@@ -6,25 +6,39 @@
 //   chunk_cosine_sim            :49-56   S[i][j] = <d1_i/|d1_i|, d2_j/|d2_j|>   (python loop over T tokens)
 //   sim_1, nn_1 = max(S, -1)    :80      best current-frame token for every desired-frame token
 //   sim_2, nn_2 = max(S, -2)    :81      and the reverse; first index on ties
-// The arithmetic is exact fp32 on the f32 MFMA (v_mfma_f32_16x16x4_f32) in every precision mode.
+// The arithmetic is exact fp32 on the f32 MFMA (v_mfma_f32_16x16x4_f32): in the fp32 mode always, in the 16-bit modes up to 1023
+// tokens.  From 1024 tokens on the 16-bit modes (whose descriptors carry the bf16 / fp16 forward's ~1e-2 error anyway) take the
+// same Gram on the f16 matrix cores at 16x the rate from a two-term split x * 2^10 = hi + lo (fp16 each, 22 significant bits):
+//   S * 2^20 = hi1.hi2 + hi1.lo2 + lo1.hi2      (the dropped lo1.lo2 term is < 2^-22 relative)
+// as ONE contraction over 3 D: desired rows are stored [hi | hi | lo], current rows [hi | lo | hi] (split_desc_kernel).
+// ViT-B/8 448² (3136 tokens): 156 us -> see profiles/r02_notes.md.
 #include "gemm_core.h"
 #include "kernels.h"
 
 namespace vitvs {
 
-template <int BM, int BN, int KG>
-__global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
+// E: float (Dp = descriptor length, scale 1) or f16 (Dp = 3 x descriptor length of the split rows, scale 2^-20)
+template <typename E, int BM, int BN, int KG>
+__global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const E* __restrict__ dn, int T, int Dp, int n_pairs,
                                                           int des_shared, unsigned long long* __restrict__ row_best,
                                                           unsigned long long* __restrict__ col_best) {
     using Tile = GemmTile<BM, BN, KG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     const int n_des = des_shared ? 1 : n_pairs;
-    const float* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;   // desired frame tokens (rows i)
-    const float* d2 = dn + (size_t)(n_des + b) * T * Dp;            // current frame tokens (cols j)
+    const E* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;   // desired frame tokens (rows i)
+    const E* d2 = dn + (size_t)(n_des + b) * T * Dp;            // current frame tokens (cols j)
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     f32x4 acc[Tile::NT][Tile::MT];
-    gemm_mainloop<float, BM, BN, KG>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    gemm_mainloop<E, BM, BN, KG>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
+    if constexpr (sizeof(E) == 2) {                                 // undo the 2^10 x 2^10 of the split (exact)
+#pragma unroll
+        for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < Tile::MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ni][mi][r] *= 0x1p-20f;
+    }
     // with two k-groups each group holds full sums only for the column tiles it owns; mask the rest
     const int kg = (KG == 2) ? k_group() : 0;
 #pragma unroll
@@ -135,6 +149,65 @@ int launch_encode_best(const int32_t* nn1, const int32_t* nn2, const float* sim1
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// dn fp32 [frames][T][Dp] -> dh fp16 [frames][T][3 Dp]: frames below n_des are desired frames (rows of the Gram), the rest current
+__global__ __launch_bounds__(256) void split_desc_kernel(const float* __restrict__ dn, f16* __restrict__ dh, int Dp, long chunks,
+                                                         long des_chunks) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;           // one 8-element chunk of one row
+    if (c >= chunks) return;
+    const int per_row = Dp >> 3;
+    const long row = c / per_row;
+    const int col = (int)(c - row * per_row) << 3;
+    const float4 a = *reinterpret_cast<const float4*>(dn + row * Dp + col);
+    const float4 b = *reinterpret_cast<const float4*>(dn + row * Dp + col + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float s = x[i] * 1024.f;                             // |x| <= 1: no overflow; exact
+        const f16 h = (f16)s;
+        hi[i] = h;
+        lo[i] = (f16)(s - (float)h);                               // exact difference, rounded once
+    }
+    f16* dst = dh + row * (3l * Dp) + col;
+    const bool desired = c < des_chunks;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + Dp) = desired ? hi : lo;
+    *reinterpret_cast<f16x8*>(dst + 2 * Dp) = desired ? lo : hi;
+}
+
+size_t gram_split_elems(int n_frames, int T, int Dp) { return (size_t)n_frames * T * 3 * Dp; }
+
+int launch_split_desc(const float* dn, void* dh, int T, int Dp, int n_pairs, int des_shared, hipStream_t stream) {
+    if (T <= 0 || n_pairs <= 0 || (Dp % 64) != 0 || !dh) return -2;
+    const int n_des = des_shared ? 1 : n_pairs, n_frames = n_des + n_pairs;
+    if ((long)n_frames * T * 3 * Dp * 2 >= (1l << 32)) return -2;  // 32-bit operand offsets in the main loop
+    const long chunks = (long)n_frames * T * (Dp >> 3), des_chunks = (long)n_des * T * (Dp >> 3);
+    launch(split_desc_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, dn, (f16*)dh, Dp, chunks, des_chunks);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
+                             unsigned long long* col_best, hipStream_t stream) {
+    if (T <= 0 || n_pairs <= 0 || (Dp % 64) != 0 || !dh) return -2;
+    const long t128 = (long)((T + 127) / 128) * ((T + 127) / 128) * n_pairs;
+    if (t128 >= 256) {                                             // enough 128 x 128 tiles for every CU (3136 tokens: 625)
+        using Tile = GemmTile<128, 128, 1>;
+        static std::atomic<unsigned long long> raised{0};
+        if (raise_lds_limit(reinterpret_cast<const void*>(&gram_argmax_kernel<f16, 128, 128, 1>), Tile::LDS_BYTES, raised)) return -1;
+        dim3 grid((T + 127) / 128, (T + 127) / 128, n_pairs);
+        launch((gram_argmax_kernel<f16, 128, 128, 1>), grid, dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T, 3 * Dp, n_pairs,
+               des_shared, row_best, col_best);
+    } else {                                                       // 1369 tokens: 121 tiles of 128 x 128, 484 of 64 x 64
+        using Tile = GemmTile<64, 64, 1>;
+        static std::atomic<unsigned long long> raised{0};
+        if (raise_lds_limit(reinterpret_cast<const void*>(&gram_argmax_kernel<f16, 64, 64, 1>), Tile::LDS_BYTES, raised)) return -1;
+        dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
+        launch((gram_argmax_kernel<f16, 64, 64, 1>), grid, dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T, 3 * Dp, n_pairs,
+               des_shared, row_best, col_best);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
                        unsigned long long* col_best, hipStream_t stream) {
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
@@ -143,12 +216,12 @@ int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shar
         // few tokens: 32x32 tiles (49 workgroups at T = 196 instead of 16) with two k-groups
         using Tile = GemmTile<32, 32, 2>;
         dim3 g32((T + 31) / 32, (T + 31) / 32, n_pairs);
-        launch(gram_argmax_kernel<32, 32, 2>, g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, dn, T, Dp, n_pairs, des_shared,
+        launch((gram_argmax_kernel<float, 32, 32, 2>), g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, dn, T, Dp, n_pairs, des_shared,
                                                                                        row_best, col_best);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
-    launch(gram_argmax_kernel<64, 64, 1>, grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, row_best, col_best);
+    launch((gram_argmax_kernel<float, 64, 64, 1>), grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, row_best, col_best);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -155,6 +155,12 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
 int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shared,
                        unsigned long long* row_best, unsigned long long* col_best, hipStream_t stream);
 // Optional dense similarity matrix (tests / debugging): S[b][i][j].
+// 16-bit modes from 1024 tokens on: hi / lo fp16 split of the descriptors into `dh` (gram_split_elems fp16 elements), then the
+// Gram on the f16 matrix cores (correspond.hip)
+size_t gram_split_elems(int n_frames, int T, int Dp);
+int launch_split_desc(const float* dn, void* dh, int T, int Dp, int n_pairs, int des_shared, hipStream_t stream);
+int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
+                             unsigned long long* col_best, hipStream_t stream);
 int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream);
 
 // packed keys <-> (nn_1, sim_1, nn_2) tables for the standalone correspondence / servo entry points
