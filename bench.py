@@ -499,39 +499,21 @@ def run_rank(args):
     fl = sum(work[c][0] * kernels[c]["launches_per_step"] for c in members) / launches
     by = sum(work[c][1] * kernels[c]["launches_per_step"] for c in members) / launches
 
-    def big_tile(m, n, kk, s_):   # mirror of big_tile_width() in csrc/gemm_big.hip
-        if es == 4 or kk % (s_ * 64) or kk // s_ < 128:
-            return 0
-        ny_ = -(-m // 256)
-        if n % 256 == 0 and 120 <= ny_ * (n // 256) * s_ <= 256:
-            return 256
-        if n % 128 == 0 and ny_ * (n // 128) * s_ >= 96:
-            return 128
-        return 0
-
-    def linear_symbol(m, n, kk, s_, epi_small, epi_big):   # mirror of the tile choice in csrc/gemm.hip / gemm_big.hip
-        bn = big_tile(m, n, kk, s_)
-        if bn:
-            return f"linear_big_kernel<{prec_tag},256x{bn}>:{epi_big}"
-        if s_ == 1 and n % 128 == 0 and -(-m // 128) * (n // 128) >= 256:
-            return f"linear_kernel<{prec_tag},128,128,1>:{epi_small}"
-        if epi_small == "EpiPartial":
-            tiles = -(-m // 64) * (n // 64) * s_
-            return f"linear_kernel<{prec_tag}," + ("64,64,2" if tiles <= 256 and (kk // s_ // (128 // es)) >= 4 else "64,64,1") + ">:EpiPartial"
-        best, bn_ = -1, 64
-        for c in (128, 96, 64):
-            if n % c == 0 and -(-m // 64) * (n // c) <= 256 and -(-m // 64) * (n // c) > best:
-                best, bn_ = -(-m // 64) * (n // c), c
-        if best < 0:
-            bn_ = 128 if n % 128 == 0 else 64
-        kg = 2 if (-(-m // 64) * (n // bn_) <= 256 and kk // (128 // es) >= 4 and (kk // (128 // es)) % 2 == 0) else 1
-        return f"linear_kernel<{prec_tag},64,{bn_},{kg}>:EpiStore"
+    def linear_symbol(m, n, kk, s_, partial):   # the kernel symbol of the tile the LIBRARY reports for this layer (no mirror)
+        import ctypes
+        tile = (ctypes.c_int32 * 3)()
+        prec_id = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16}[prec_tag]
+        if eng.lib.vitvs_op_linear_tile(prec_id, m, n, kk, s_ if partial else 0, tile) != 0:
+            return None
+        if tile[2] == 0:
+            return f"linear_big_kernel<{prec_tag},{tile[0]}x{tile[1]}>:" + ("BigPartial" if partial else "BigStore")
+        return f"linear_kernel<{prec_tag},{tile[0]},{tile[1]},{tile[2]}>:" + ("EpiPartial" if partial else "EpiStore")
     m_all = 2 * B * cfg.seq
     bk_es = 128 // es
-    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es), "EpiPartial", "BigPartial"),
+    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es), True),
               "residual_ln": f"residual_ln_kernel<{prec_tag}>",
-              "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, "EpiStore", "BigStore"),
-              "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, "EpiStore", "BigStore"),
+              "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, False),
+              "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, False),
               "attention": "attention_f32_kernel" if prec_tag == "f32" else
                            (f"attention_16_long_kernel<{prec_tag}>" if cfg.seq >= 512 else
                             (f"attention_16_short_kernel<{prec_tag}>" if cfg.seq <= 256 and -(-cfg.seq // 16) * cfg.heads * 2 * B <= 640

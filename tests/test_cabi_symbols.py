@@ -77,3 +77,36 @@ def test_bench_split_k_mirror_matches_the_library_plan():
         for m in (197, 394, 788, 1576, 3152, 970, 2740, 6274):
             for n, k in ((768, 768), (768, 3072), (384, 384), (384, 1536), (1024, 1024), (1024, 4096), (768, 640), (768, 192)):
                 assert bench.split_k(m, n, k, bk) == lib.vitvs_op_splitk_slices(prec, m, n, k), (prec, m, n, k)
+
+
+def test_linear_tile_plan_of_the_library():
+    """The tile family per layer shape is host arithmetic (vitvs_op_linear_tile, no device call).  Pins the measured choices:
+    64-row tiles while they cover the layer in one round of workgroups, 256-row tiles where they would need a second one, and
+    between 256 x 256 and 256 x 128 the one that leaves the busiest CU the least work (profiles/r02_notes.md section 2)."""
+    import ctypes
+    from vitvs_amd import _lib
+    lib = _lib.load()
+
+    def plan(prec, m, n, k, slices=0):
+        t = (ctypes.c_int32 * 3)()
+        assert lib.vitvs_op_linear_tile(prec, m, n, k, slices, t) == 0
+        return tuple(t)
+    b = _lib.BF16
+    assert plan(b, 394, 3072, 768) == (64, 96, 2)            # one frame pair: fc1, qkv, the K-sliced narrow layers
+    assert plan(b, 394, 2304, 768) == (64, 64, 2)
+    assert plan(b, 394, 768, 3072, 3) == (64, 64, 2)
+    assert plan(b, 788, 2304, 768) == (64, 128, 2)           # two pairs: still one round of 64-row tiles
+    assert plan(b, 788, 3072, 768) == (256, 128, 0)
+    assert plan(b, 985, 2304, 768) == (256, 128, 0)          # rotation search (5 images): a second round of 64-row tiles loses
+    assert plan(b, 2364, 3072, 768) == (256, 128, 0)         # 120 tiles of 256 x 256 would leave half the CUs idle
+    assert plan(b, 3152, 3072, 768) == (256, 256, 0)         # 8 pairs: 156 tiles in one round beat 312 in two
+    assert plan(b, 3152, 2304, 768) == (256, 128, 0)
+    assert plan(b, 3152, 768, 3072, 3) == (256, 128, 0)
+    assert plan(b, 3152, 768, 768, 1) == (64, 64, 1)
+    assert plan(b, 6274, 2304, 768) == (256, 256, 0)         # ViT-B/8 448
+    assert plan(b, 6274, 3072, 768) == (256, 128, 0)
+    assert plan(b, 2740, 3072, 1024) == (256, 256, 0)        # ViT-L/14 518
+    assert plan(b, 2740, 1024, 4096, 2) == (256, 128, 0)
+    assert plan(_lib.F32, 6274, 3072, 768) == (128, 128, 1)  # fp32 never takes the 256-row kernels
+    t = (ctypes.c_int32 * 3)()
+    assert lib.vitvs_op_linear_tile(b, 394, 768, 3072, 5, t) != 0   # 3072 is not a multiple of 5 k-tiles

@@ -47,7 +47,8 @@ PRECS = [("fp32", _lib.F32, torch.float32, F32_TOL), ("bf16", _lib.BF16, torch.b
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("M,N,K,gelu", [(394, 384, 128, 0), (394, 2304, 768, 0), (77, 512, 192, 1), (1200, 3072, 768, 1),
-                                        (64, 64, 64, 0), (5, 128, 640, 1), (6274, 3072, 768, 1), (3170, 2304, 768, 0)])
+                                        (64, 64, 64, 0), (5, 128, 640, 1), (6274, 3072, 768, 1), (3170, 2304, 768, 0),
+                                        (985, 2304, 768, 0), (2364, 3072, 768, 1), (788, 3072, 768, 1)])
 def test_linear(lib, name, prec, dtype, tol, M, N, K, gelu):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = _mk((M, K), g).to(dtype)

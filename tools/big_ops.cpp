@@ -71,6 +71,20 @@ int main(int argc, char** argv) {
         {"1500x2304 K=128  ", 1500, 2304, 128, 0, 0},  {"1500x2304 K=768  ", 1500, 2304, 768, 0, 0},
         {"1500x2304 K=3072 ", 1500, 2304, 3072, 0, 0},
     };
+    // "mid": 2..6 frame pairs (788..2364 rows) through the four layer shapes of ViT-B/16: where does each tile family win?
+    const bool mid_mode = argc > 1 && !strcmp(argv[1], "mid");
+    std::vector<Shape> mid_shapes;
+    static char mid_names[64][24];
+    if (mid_mode) {
+        int q = 0;
+        for (int rows : {788, 985, 1182, 1576, 1970, 2364})
+            for (int layer = 0; layer < 4; ++layer) {
+                const int N = layer == 0 ? 2304 : layer == 1 ? 3072 : 768, K = layer == 2 ? 3072 : 768;
+                snprintf(mid_names[q], sizeof(mid_names[q]), "%4d rows %s", rows, layer == 0 ? "qkv " : layer == 1 ? "fc1 " : layer == 2 ? "fc2 " : "proj");
+                mid_shapes.push_back(Shape{mid_names[q], rows, N, K, layer == 1, layer >= 2 ? -1 : 0});
+                ++q;
+            }
+    }
     // "slices": the narrow layers at 3152 / 2740 rows with 1..4 K slices (the forward adds ~1.8 us of residual_ln per extra slice)
     const bool slices_mode = argc > 1 && !strcmp(argv[1], "slices");
     const Shape slice_shapes[] = {
@@ -90,19 +104,21 @@ int main(int argc, char** argv) {
     if (attn_only) todo.clear();
     else if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
     else if (slices_mode) todo.assign(std::begin(slice_shapes), std::end(slice_shapes));
+    else if (mid_mode) todo = mid_shapes;
     else todo.assign(std::begin(shapes), std::end(shapes));
     for (const Shape& s : todo) {
         void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
         void* Wt[nsets];
         for (int i = 0; i < nsets; ++i) Wt[i] = rand_bf16((size_t)s.N * s.K, 0.05f, 2 + i);
         void* out;
-        const int sl = s.slices;
+        const int sl = s.slices < 0 ? vitvs_op_splitk_slices(VITVS_BF16, s.M, s.N, s.K) : s.slices;   // -1: the library's choice
         CHECK(hipMalloc(&out, (size_t)(sl ? sl * 4 : 2) * s.M * s.N + 256));
         float* bias;
         CHECK(hipMalloc((void**)&bias, s.N * 4));
         CHECK(hipMemset(bias, 0, s.N * 4));
         const double flop = 2.0 * s.M * s.N * s.K;
         printf("%-20s %6d %6d %6d |", s.name, s.M, s.N, s.K);
+        if (s.slices < 0) printf(" %d slice(s) |", sl);
         for (int variant : {0, 1, 256, 128}) {
             int turn = 0;
             const double us = run(st, fast ? 20 : 60, [&] {
@@ -116,7 +132,7 @@ int main(int argc, char** argv) {
         CHECK(hipFree(A)); CHECK(hipFree(out)); CHECK(hipFree(bias));
         for (int i = 0; i < nsets; ++i) CHECK(hipFree(Wt[i]));
     }
-    if (sweep || slices_mode) return 0;
+    if (sweep || slices_mode || mid_mode) return 0;
     // long-sequence attention: (images, tokens, heads)
     const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
     typedef int (*set_lds_t)(int);

@@ -899,6 +899,13 @@ int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_
     DeviceScope dev(nullptr);
     return launch_attention(to_prec(precision), qkv, out, n_img, N, H, as_stream(stream));
 }
+int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int32_t slices, int32_t* tile) {
+    if (!tile) return -1;
+    int t[3] = {0, 0, 0};
+    const int rc = linear_tile_plan(to_prec(precision), M, N, K, slices > 0 ? slices : 1, slices > 0, t);
+    tile[0] = t[0]; tile[1] = t[1]; tile[2] = t[2];
+    return rc;
+}
 int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
     return splitk_slices(to_prec(precision), M, N, K);
 }

@@ -281,7 +281,7 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    if (const int bn = big_tile_width(p, M, N, K, 1)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream);
+    if (const int bn = big_tile_width(p, M, N, K, 1, false)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream);
     return launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, stream);
 }
 
@@ -332,7 +332,7 @@ int splitk_slices(Precision p, int M, int N, int K) {
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
                           hipStream_t stream) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
-    if (const int bn = big_tile_width(p, M, N, K, splits))
+    if (const int bn = big_tile_width(p, M, N, K, splits, true))
         return launch_linear_big(p, bn, A, W, nullptr, part, M, N, K, splits, 0, true, stream);
     return launch_linear_partial_classic(p, A, W, part, M, N, K, splits, stream);
 }
@@ -344,6 +344,15 @@ int launch_linear_partial_classic(Precision p, const void* A, const void* W, flo
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
     if (p == PREC_F16) return launch_tiles64<f16, EpiPartial>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
     return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
+}
+
+int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial, int out[3]) {
+    if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0 || (!partial && splits != 1)) return -2;
+    if (const int bn = big_tile_width(p, M, N, K, splits, partial)) { out[0] = 256; out[1] = bn; out[2] = 0; return 0; }
+    if (big_problem(M, N, splits)) { out[0] = 128; out[1] = 128; out[2] = 1; return 0; }
+    const TilePlan pl = plan_tiles(M, N, K / splits / k_tile(p), splits, partial);
+    out[0] = 64; out[1] = pl.bn; out[2] = pl.kg;
+    return 0;
 }
 
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,

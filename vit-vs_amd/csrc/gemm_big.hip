@@ -394,15 +394,27 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
 //     (6274x3072: 46 vs 50 / 49; 6274x768x3072: 38 vs 55 / 46; 3152x2304: 16 vs 21 / 19; 788x3072: 15 vs 23 / 20)
 //   * fewer tiles than that (narrow layers at 3152 / 2740 rows): the 2-workgroups-per-CU tiles of gemm.hip win or tie.
 // Returns 0 (use gemm.hip), 256 or 128.
-int big_tile_width(Precision p, int M, int N, int K, int splits) {
+int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
-    const long ny = (M + 255) / 256;
-    if (N % 256 == 0 && N / 256 <= 255) {
-        const long t256 = ny * (N / 256) * splits;
-        if (t256 >= 120 && t256 <= 256) return 256;
+    // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
+    // 11.9 us on 256 x 128 tiles); where they need a second round the 256-row tiles win from 64 tiles up (985 x 2304: 18.4 vs
+    // 11.9 us).  Between the two tile families of this file the busiest CU's share decides: a 256 x 128 tile costs 0.62 of a
+    // 256 x 256 one (half the k-loop, the same fixed cost), and a CU walks ceil(tiles / 256) of them
+    // (2364 x 3072: 120 tiles of 256 x 256 25.7 us, 240 of 256 x 128 17.4 us; 3152 x 3072: 156 -> 25.3 us, 312 -> 29.8 us).
+    const long mt = (M + 63) / 64;
+    for (int c : {128, 96, 64}) {
+        if (partial && c != 64) continue;                         // the partial-sum kernels of gemm.hip are 64 wide
+        if (N % c == 0 && mt * (N / c) * splits <= 256) return 0;
     }
-    if (N % 128 == 0 && N / 128 <= 255 && ny * (N / 128) * splits >= 96) return 128;
-    return 0;
+    const long ny = (M + 255) / 256;
+    if (N % 128 != 0 || N / 128 > 255) return 0;
+    const long t128 = ny * (N / 128) * splits;
+    if (t128 < (partial ? 96 : 64)) return 0;
+    if (N % 256 == 0) {
+        const long t256 = ny * (N / 256) * splits;
+        if ((double)((t256 + 255) / 256) < 0.62 * (double)((t128 + 255) / 256)) return 256;
+    }
+    return 128;
 }
 
 template <typename T>

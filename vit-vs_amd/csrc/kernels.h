@@ -80,7 +80,9 @@ int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const floa
 
 // ---- gemm_big.hip: 256-row tiles for many-row problems (16-bit operands) --------------------------------
 // big_tile_width: 0 = not applicable (use the tiles of gemm.hip), else the column-tile width (256 or 128) to pass on.
-int big_tile_width(Precision p, int M, int N, int K, int splits);
+int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial);
+// (BM, BN, KG) of the kernel launch_linear (partial = false, splits = 1) / launch_linear_partial picks; KG = 0: 256-row tiles
+int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial, int out[3]);
 // partial = false: out[m][n] = act(sum + bias[n]) in precision p; partial = true: out = fp32 part[z][m][n], z < splits.
 int launch_linear_big(Precision p, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                       int splits, int gelu, bool partial, hipStream_t stream);
