@@ -188,7 +188,7 @@ def test_split_k_pair(lib, name, prec, dtype, tol, M, D, K, use_ls, use_ln):
 
 
 @pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
-@pytest.mark.parametrize("variant", [256, 128, 1])
+@pytest.mark.parametrize("variant", [256, 128, 1, 2])
 @pytest.mark.parametrize("M,N,K,gelu", [(6274, 2304, 768, 0), (2740, 1024, 1024, 1), (1025, 256, 128, 0), (3152, 768, 3072, 1),
                                         (300, 512, 192, 0)])
 def test_linear_tile_families_agree_with_the_reference(lib, name, prec, dtype, tol, variant, M, N, K, gelu):
@@ -212,7 +212,7 @@ def test_linear_tile_families_agree_with_the_reference(lib, name, prec, dtype, t
     assert _rel(out[:M].cpu(), ref) <= tol
 
 
-@pytest.mark.parametrize("variant", [256, 128, 1])
+@pytest.mark.parametrize("variant", [256, 128, 1, 2])
 @pytest.mark.parametrize("M,N,K,slices", [(6274, 768, 3072, 3), (2740, 1024, 1024, 2), (1500, 256, 768, 1)])
 def test_linear_partial_tile_families(lib, variant, M, N, K, slices):
     """Split-K partial sums from both tile families: slice z holds exactly the products of its K range (fp32)."""

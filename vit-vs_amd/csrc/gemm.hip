@@ -294,6 +294,20 @@ int launch_linear_classic(Precision p, const void* A, const void* W, const float
     return launch_tiles<bf16, EpiStore<bf16>>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
 }
 
+// experiments (vitvs_op_linear_variant 2): the 128 x 128 tiles of this file whatever the shape
+int launch_linear_128(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int gelu,
+                      int splits, bool partial, hipStream_t stream) {
+    if (!shapes_ok(p, M, N, K) || N % 128 != 0 || p == PREC_F32) return -2;
+    if (partial) {
+        const EpiArgs e{out, nullptr, nullptr, 0};
+        if (p == PREC_F16) return launch_one<f16, 128, 1, EpiPartial, 128>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
+        return launch_one<bf16, 128, 1, EpiPartial, 128>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
+    }
+    const EpiArgs e{out, bias, nullptr, gelu};
+    if (p == PREC_F16) return launch_one<f16, 128, 1, EpiStore<f16>, 128>((const f16*)A, (const f16*)W, M, N, K, e, stream, 1);
+    return launch_one<bf16, 128, 1, EpiStore<bf16>, 128>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, 1);
+}
+
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
                            int M, int N, int K, hipStream_t stream) {
     if (!shapes_ok(p, M, N, K)) return -2;

@@ -62,6 +62,8 @@ inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream);
 // the same two operators restricted to the tiles of gemm.hip (no hand-over to gemm_big.hip)
+int launch_linear_128(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int gelu,
+                      int splits, bool partial, hipStream_t stream);
 int launch_linear_classic(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                           int gelu, hipStream_t stream);
 int launch_linear_partial_classic(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
