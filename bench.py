@@ -515,8 +515,9 @@ def run_rank(args):
               "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, False),
               "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, False),
               "attention": "attention_f32_kernel" if prec_tag == "f32" else
-                           (f"attention_16_long_kernel<{prec_tag}>" if cfg.seq >= 512 else
-                            (f"attention_16_short_kernel<{prec_tag}>" if cfg.seq <= 256 and -(-cfg.seq // 16) * cfg.heads * 2 * B <= 640
+                           (f"attention_16_short_kernel<{prec_tag}>" if cfg.seq <= 256 and -(-cfg.seq // 16) * cfg.heads * 2 * B <= 640 else
+                            (f"attention_16_long_kernel<{prec_tag}>"
+                             if cfg.seq >= 512 or (cfg.seq >= 128 and -(-cfg.seq // 64) * cfg.heads * 2 * B > 256)
                              else f"attention_16_kernel<{prec_tag}>"))}.get(dom, dom)
     # HBM traffic (PMC) comes from separate rocprofv3 --pmc passes of this same command, never from this run: the line
     # says which committed file and which commit of the kernels it was measured on, and mixes it into no live ratio.

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <array>
 #include <functional>
 #include <vector>
 
@@ -99,7 +100,7 @@ int main(int argc, char** argv) {
     printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, 64-row tiles, 256x256, 256x128, 128x128");
     // "occ": attention only, on a probe build of the library, with the workgroups per CU limited through their LDS size
     const bool occ = argc > 1 && !strcmp(argv[1], "occ");
-    const bool attn_only = occ || (argc > 1 && !strcmp(argv[1], "attn"));
+    const bool attn_only = occ || (argc > 1 && (!strcmp(argv[1], "attn") || !strcmp(argv[1], "attnmid")));
     std::vector<Shape> todo;
     if (attn_only) todo.clear();
     else if (sweep) todo.assign(std::begin(sweep_shapes), std::end(sweep_shapes));
@@ -134,7 +135,16 @@ int main(int argc, char** argv) {
     }
     if (sweep || slices_mode || mid_mode) return 0;
     // long-sequence attention: (images, tokens, heads)
-    const int att[][3] = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12}, {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
+    // "attn": the long sequences of the 448 / 518 inputs and batches of short ones; "attnmid": 3..16 images of 197 / 485 tokens
+    const bool attn_mid = argc > 1 && !strcmp(argv[1], "attnmid");
+    std::vector<std::array<int, 3>> att = {{2, 3137, 12}, {2, 1370, 16}, {16, 197, 12}, {2, 785, 12}, {8, 785, 12}, {4, 3137, 12},
+                                           {2, 577, 12}, {8, 197, 12}, {4, 197, 12}, {16, 257, 12}, {16, 485, 6}};
+    if (attn_mid) {
+        att.clear();
+        for (int n : {3, 4, 5, 6, 7, 8, 10, 12, 16}) att.push_back({n, 197, 12});
+        for (int n : {2, 3, 4, 5, 6, 8, 10, 12}) att.push_back({n, 485, 6});
+        for (int n : {2, 4, 6, 8}) att.push_back({n, 257, 16});
+    }
     typedef int (*set_lds_t)(int);
     set_lds_t set_lds = (set_lds_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_attn_lds");
     if (occ && !set_lds) { printf("occ needs a probe build of the library\n"); return 1; }

@@ -905,10 +905,11 @@ static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, 
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
                out, N, D, n_img);
-    } else if ((N >= 512 || (N >= 128 && (long)nt * H * n_img >= 384)) && (long)n_img * N * 6 * D < (1l << 32)) {
-        // 128 queries per workgroup: from 512 tokens on, and for shorter sequences once the 64-query kernel would put more
-        // than ~1.5 workgroups on every CU (each re-reads its head's K / V): 16 x 197 x 12 heads 12.6 -> 10.7 us,
-        // 16 x 485 x 6 heads 20.1 -> 16.9 us; equal at 4 x 197 and 8 x 197
+    } else if ((N >= 512 || (N >= 128 && (long)nt * H * n_img > 256)) && (long)n_img * N * 6 * D < (1l << 32)) {
+        // 128 queries per workgroup: from 512 tokens on, and for shorter sequences once the 64-query kernel no longer fits its
+        // 512-thread one-workgroup-per-CU form (each of its workgroups re-reads its head's K / V): 16 x 197 x 12 heads
+        // 12.7 -> 10.7 us, 6 x 485 x 6 heads 12.9 -> 10.9 us; equal at 6..12 x 197; below that bound the 64-query kernel wins
+        // (5 x 197, the rotation search: 5.3 vs 7.2 us; 5 x 485 x 6: 8.0 vs 10.7 us)  [tools/big_ops attnmid]
         const int sp = attention_splits(n_img, N, H);
         const int units = ((N + 127) / 128) * H * n_img * sp;
         if (sp > 1) {
