@@ -33,6 +33,7 @@ tools/big_ops > $O/big_ops.txt 2>&1
 tools/big_ops mid > $O/big_ops_mid.txt 2>&1
 tools/big_ops slices > $O/big_ops_slices.txt 2>&1
 tools/big_ops sweep > $O/big_ops_k_sweep.txt 2>&1
+tools/big_ops attnmid > $O/attention_mid.txt 2>&1
 LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops attn > $O/attention_probe.txt 2>&1
 LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops occ > $O/attention_occupancy.txt 2>&1
 # keep only the small summaries in the merged output
