@@ -392,14 +392,15 @@ def run_rank(args):
 
     stream = torch.cuda.Stream(device=dev)
 
-    def make_step(engine):
+    def make_step(engine, goal=None):
+        goal = I_des if goal is None else None          # goal = "cached": the engine holds the goal (Engine.set_goal)
         def step(i):
             # a fresh visiting order per update, already resident (launches are eager, so the pointer may change)
             vi = v_slots[i & 1] if async_gather else v
             if dense:
-                engine.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, vi, status)
+                engine.compute_velocity_dev(I_cur, goal, Z, K, _lib.SELECT_DENSE, None, None, False, vi, status)
             else:
-                engine.compute_velocity_dev(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, vi, status)
+                engine.compute_velocity_dev(I_cur, goal, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, vi, status)
             if async_gather:
                 gather.post(vi, i)
             elif multi:
@@ -468,6 +469,18 @@ def run_rank(args):
                 secondary["parity"] = parity_block(eng32, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K,
                                                    orders[0, 0], _lib)
             eng32.close()
+
+        # NOT the headline: the same updates with the goal frame's tokens computed once (vitvs_set_goal_dev) — what a servo
+        # loop with a fixed goal image can use; the reference (and `value`) recompute them on every update
+        goal_cached = None
+        if world == 1 and rank == 0 and not args.no_secondary and not dense:
+            eng.set_goal(I_des)
+            c_steps, c_warm = max(10, args.steps // 2), max(3, args.warmup // 2)
+            elc = timed_updates(eng, make_step(eng, "cached"), fence, c_warm, c_steps, dev)
+            goal_cached = dict(metric="servo_updates_per_sec", value=round(B * c_steps / elc, 2), unit="updates/s", steps=c_steps,
+                               warmup=c_warm, ms_per_step=round(elc / c_steps * 1e3, 4), dtype=args.precision,
+                               note="goal tokens cached (vitvs_set_goal_dev): only the current frame is forwarded; the "
+                                    "reference recomputes I_des every update, and so does `value`")
 
     updates = world * B * args.steps
     value = updates / elapsed
@@ -565,6 +578,7 @@ def run_rank(args):
         cpu_baseline=None,
         parity=parity,
         secondary=secondary,
+        goal_cached=goal_cached,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),
                   tflops=round(cfg.flops_per_pair(binned) * value / world / 1e12, 3),
                   frac_of_mfma_peak=round(cfg.flops_per_pair(binned) * value / world / PEAK_MFMA[args.precision], 5),

@@ -102,7 +102,8 @@ VITVS_API int vitvs_weights_ready(const vitvs_handle* h);
  * up to the raw (pre-EMA) twist (vitvs_v2.py:464-523, 588-622).
  *   n_pairs          frame pairs in this call (<= max_pairs)
  *   I_cur, I_des     uint8 [n_pairs][S][S][3]; if des_shared != 0, I_des is ONE image used for all
- *                    pairs (rotation compensation, vitvs_v2.py:1151-1189)
+ *                    pairs (rotation compensation, vitvs_v2.py:1151-1189); I_des == NULL: the goal cached by
+ *                    vitvs_set_goal[_dev] (below)
  *   Z_mm             uint16 [n_pairs][v_max][u_max], or NULL -> status NO_DEPTH
  *   K                double [n_pairs][4] = fx, fy, cx, cy
  *   select_mode      vitvs_select; `selection` int32: EXPLICIT [n_pairs][num_pairs] token ids with
@@ -121,6 +122,17 @@ VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uin
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                            const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
                            int32_t* status);
+
+/* --- a goal image that does not change between updates ---------------------------------------------
+ * The reference recomputes the goal image's tokens on every update (vitvs_v2.py:482-487), and so does the call above
+ * whenever it is given I_des (the benchmarked form).  A servo loop keeps one goal image for a whole run: these two entry
+ * points forward n_goal goal frames ONCE (uint8 [n_goal][S][S][3]; n_goal = the later calls' n_pairs, or 1 for des_shared
+ * calls) and keep their descriptors in the handle; a later vitvs_compute_velocity[_dev] with I_des == NULL then forwards
+ * only the current frames.  The cache is dropped by any call that forwards frames of its own choice through the handle
+ * (a velocity call WITH I_des, vitvs_forward_tokens_dev, vitvs_extract_*): a NULL I_des without a matching cached goal is
+ * error -5.  Results equal the recomputing call's up to the summation order of the GEMMs (the row count differs). */
+VITVS_API int vitvs_set_goal_dev(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des, void* stream);
+VITVS_API int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des);
 
 /* --- in front of it: camera frame -> extractor input -----------------------------------------------
  * goal_image.resize((S, S)) / latest_pil_image.resize((S, S)) (vitvs_v2.py:474-475; PIL default filter BICUBIC,

@@ -262,6 +262,63 @@ def test_compute_velocity_fp32_matches_reference(key, tag):
     assert _rel_l2(v, case["v_c"]) <= 1e-9 <= VC_TOL
 
 
+@pytest.mark.parametrize("key,tag", [("vitb16_224", "plain"), ("vits14_308", "binned")])
+def test_cached_goal_gives_the_reference_update(key, tag):
+    """vitvs_set_goal_dev: the goal frame forwarded once, later calls pass I_des = None and forward only the current frame.
+    Against the reference-generated fixture exactly like the recomputing call (bit-exact tables, v_c <= 1e-9), twice in a
+    row (the cache survives a cached call), and the cache is dropped by any call that forwards frames of its own."""
+    from vitvs_amd.engine import VitvsError
+    blob = load_golden(f"e2e_{key}.npz")
+    case = golden_case(blob, tag)
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=(tag == "binned"))
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd)
+    sel = _ids(case["points1"], cfg.grid)
+    depth = synth.depth_pattern()
+    with pytest.raises(VitvsError):                       # nothing cached yet
+        eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+    eng.set_goal(des)
+    for _ in range(2):
+        v, st = eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+        det = eng.last_details(1)
+        assert int(st[0]) == 0
+        assert np.array_equal(det["nn_1"][0], case["nn_1"]) and np.array_equal(det["nn_2"][0], case["nn_2"])
+        np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-5)
+        assert _rel_l2(v.cpu().numpy()[0], case["v_c"]) <= 1e-9 <= VC_TOL
+    eng.forward_tokens(np.stack([cur]))                    # forwards a frame of its own: the goal rows are gone
+    with pytest.raises(VitvsError):
+        eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_cached_shared_goal_batch_matches_the_recomputing_call(precision):
+    """One cached goal against three current frames (the rotation search's layout): the same arg-max tables and twists as the
+    call that forwards the goal again, up to the GEMMs' summation order (4 images there, 3 here: other tiles)."""
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
+    pairs = [synth.frame_pair(224, 20250705 + i) for i in range(3)]
+    des = pairs[0][0]
+    cur = np.stack([p[1] for p in pairs])
+    depth = np.stack([synth.depth_pattern()] * 3)
+    eng = _engine(cfg, params, precision=precision, max_pairs=3, max_rows=196).load_state_dict(sd)
+    v_ref, s_ref = eng.compute_velocity(cur, des[None], depth, params.intrinsics(), mode=_lib.SELECT_DENSE, des_shared=True)
+    det_ref = eng.last_details(3)
+    eng.set_goal(des[None])
+    v, s_ = eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_DENSE, des_shared=True)
+    det = eng.last_details(3)
+    assert torch.equal(s_, s_ref)
+    for b in range(3):
+        a1 = float((det["nn_1"][b] == det_ref["nn_1"][b]).mean())
+        a2 = float((det["nn_2"][b] == det_ref["nn_2"][b]).mean())
+        assert a1 >= 0.99 and a2 >= 0.99, (b, a1, a2)
+        np.testing.assert_allclose(det["sim_1"][b], det_ref["sim_1"][b], rtol=0, atol=2e-5 if precision == "fp32" else 2e-2)
+        if np.array_equal(det["nn_1"][b], det_ref["nn_1"][b]) and np.array_equal(det["nn_2"][b], det_ref["nn_2"][b]):
+            assert _rel_l2(v[b].cpu().numpy(), v_ref[b].cpu().numpy()) <= 1e-9
+
+
 def _tie_tolerant_agreement(got, ref_idx, sim_ref_rows, tol):
     """Every disagreement must be a numerical tie in the oracle's similarities."""
     bad = np.nonzero(got != ref_idx)[0]

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "vitvs_weights_ready": (_I, [_P]),
     "vitvs_compute_velocity_dev": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "vitvs_compute_velocity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
+    "vitvs_set_goal_dev": (_I, [_P, _I, _P, _P]),
+    "vitvs_set_goal": (_I, [_P, _I, _P]),
     "vitvs_extract_descriptors_dev": (_I, [_P, _I, _P, _P, _P]),
     "vitvs_forward_tokens_dev": (_I, [_P, _I, _P, _P, _P]),
     "vitvs_correspond_dev": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -108,6 +108,7 @@ struct vitvs_handle {
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     bool use_graphs = false;
+    int goal_frames = 0;      // goal frames whose tokens / descriptors are cached in rows [0, goal_frames) (vitvs_set_goal_dev)
 };
 
 namespace {
@@ -322,13 +323,14 @@ ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
 // frames) on stream `st`: an independent chain of launches touching only those images' rows.
 int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* des, const uint8_t* cur, float* part,
                   hipStream_t st) {
+    if (i0 == 0) h->goal_frames = 0;            // rows of a cached goal are about to be overwritten (vitvs_set_goal_dev re-arms)
     ChainCtx cx = fill_ctx(h, i0, cnt, n_des, des, cur, part);
     if (h->desc_keys >= 0 && desc_in_forward(h)) {
         cx.want_desc = true;
         cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
         cx.desc.zero_a = h->row_best; cx.desc.zero_b = h->col_best;
         cx.desc.T = h->T;
-        cx.desc.zero_count = (i0 == 0) ? h->desc_keys : 0;
+        cx.desc.zero_count = (i0 == 0 || h->goal_frames > 0) ? h->desc_keys : 0;   // the call's only chain clears the arg-max keys
     }
     return forward_lockstep(h, &cx, 1, st);
 }
@@ -651,6 +653,7 @@ int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* de
         return set_err(h, -3, "descriptors exceed the handle's workspace");
     DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
+    h->goal_frames = 0;                         // the descriptor workspace is overwritten
     int rc = launch_normalize_rows(desc1, h->dn, T, Dp, st);
     if (!rc) rc = launch_normalize_rows(desc2, h->dn + (size_t)T * Dp, T, Dp, st);
     if (rc) return set_err(h, rc, "normalise launch failed");
@@ -690,8 +693,12 @@ struct UpdateArgs {
 
 static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
+    if (!u.I_des && h->goal_frames != n_des)
+        return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
     h->desc_keys = u.n_pairs * h->T;
-    int rc = forward_chain(h, 0, n_img, n_des, u.I_des, u.I_cur, h->part, st);
+    // cached goal: only the current frames (images n_des .. n_img - 1 of the call's list) go through the network
+    int rc = u.I_des ? forward_chain(h, 0, n_img, n_des, u.I_des, u.I_cur, h->part, st)
+                     : forward_chain(h, n_des, u.n_pairs, n_des, nullptr, u.I_cur, h->part, st);
     h->desc_keys = -1;
     if (rc) return rc;
     if (!desc_in_forward(h)) {
@@ -764,11 +771,37 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
     return 0;
 }
 
+int vitvs_set_goal_dev(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des, void* stream) {
+    if (!h || !I_des) return set_err(h, -1, "null argument");
+    if (n_goal <= 0 || n_goal > h->cfg.max_pairs) return set_err(h, -3, "n_goal exceeds max_pairs");
+    DeviceScope dev(h);
+    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
+    hipStream_t st = as_stream(stream);
+    h->desc_keys = 0;                           // plain descriptors come out of the forward's last launch; no keys to clear
+    int rc = forward_chain(h, 0, n_goal, n_goal, I_des, nullptr, h->part, st);
+    h->desc_keys = -1;
+    if (rc) return rc;
+    h->goal_frames = n_goal;                    // (binned descriptors are rebuilt from the kept tokens by every velocity call)
+    return 0;
+}
+
+int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des) {
+    if (!h || !I_des) return set_err(h, -1, "null argument");
+    if (n_goal <= 0 || n_goal > h->cfg.max_pairs) return set_err(h, -3, "n_goal exceeds max_pairs");
+    DeviceScope dev(h);
+    const size_t img = (size_t)h->cfg.img_size * h->cfg.img_size * 3;
+    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, n_goal * img, hipMemcpyHostToDevice, nullptr));
+    const int rc = vitvs_set_goal_dev(h, n_goal, h->st_des, nullptr);
+    if (rc) return rc;
+    VITVS_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
 int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                                int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                                const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
                                int32_t* status, void* stream) {
-    if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
+    if (!h || !I_cur || !K || !v_c || !status) return set_err(h, -1, "null argument");   // I_des NULL: the cached goal
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
     const int np = call_num_pairs(h, num_pairs);
     if (np > h->cfg.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
@@ -786,7 +819,7 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                            const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
                            int32_t* status) {
-    if (!h || !I_cur || !I_des || !K || !v_c || !status) return set_err(h, -1, "null argument");
+    if (!h || !I_cur || !K || !v_c || !status) return set_err(h, -1, "null argument");   // I_des NULL: the cached goal
     if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
     const vitvs_config& c = h->cfg;
     const int np = call_num_pairs(h, num_pairs);
@@ -795,7 +828,7 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     const size_t img = (size_t)c.img_size * c.img_size * 3;
     hipStream_t st = nullptr;
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_cur, I_cur, n_pairs * img, hipMemcpyHostToDevice, st));
-    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, (des_shared ? 1 : n_pairs) * img, hipMemcpyHostToDevice, st));
+    if (I_des) VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, (des_shared ? 1 : n_pairs) * img, hipMemcpyHostToDevice, st));
     if (Z_mm)
         VITVS_HIP_CHECK(hipMemcpyAsync(h->st_depth, Z_mm, (size_t)n_pairs * c.u_max * c.v_max * 2, hipMemcpyHostToDevice, st));
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_K, K, (size_t)n_pairs * 4 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -807,7 +840,7 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
         if (!selection) return set_err(h, -5, "ORDER selection needs a visiting order");
         VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * h->T * 4, hipMemcpyHostToDevice, st));
     }
-    int rc = vitvs_compute_velocity_dev(h, n_pairs, h->st_cur, h->st_des, des_shared, Z_mm ? h->st_depth : nullptr,
+    int rc = vitvs_compute_velocity_dev(h, n_pairs, h->st_cur, I_des ? h->st_des : nullptr, des_shared, Z_mm ? h->st_depth : nullptr,
                                         h->st_K, select_mode, h->st_sel, h->st_nsel, np, h->st_vc, h->st_status, st);
     if (rc) return rc;
     VITVS_HIP_CHECK(hipMemcpyAsync(v_c, h->st_vc, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -232,7 +232,17 @@ class Engine:
         return v[0], st[0]
 
     # ------------------------------------------------------------------ the hot path
-    def compute_velocity_dev(self, I_cur: torch.Tensor, I_des: torch.Tensor, Z: Optional[torch.Tensor],
+    def set_goal(self, I_des) -> "Engine":
+        """Forward the goal frame(s) once and keep their descriptors in the handle (``vitvs_set_goal_dev``): later
+        ``compute_velocity(..., I_des=None, ...)`` calls forward only the current frames.  One frame per pair of the later
+        calls, or one frame for ``des_shared`` calls.  The reference recomputes the goal every update
+        (vitvs_v2.py:482-487); the cache is for servo loops whose goal image does not change, and any call that forwards
+        other frames through the engine drops it."""
+        des = self._frames(I_des)
+        self._check(self.lib.vitvs_set_goal_dev(self.handle, int(des.shape[0]), _ptr(des), _stream_ptr(self.device)), "vitvs_set_goal_dev")
+        return self
+
+    def compute_velocity_dev(self, I_cur: torch.Tensor, I_des: Optional[torch.Tensor], Z: Optional[torch.Tensor],
                              K: torch.Tensor, mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
                              n_selected: Optional[torch.Tensor] = None, des_shared: bool = False,
                              out_v: Optional[torch.Tensor] = None, out_status: Optional[torch.Tensor] = None,
@@ -255,9 +265,9 @@ class Engine:
         """Convenience form: numpy / CPU inputs are moved to the device, then the device path runs.  ``num_pairs``:
         the reference's ``Controller.num_pairs`` for this call (default: the engine's parameters)."""
         cur = self._frames(I_cur)
-        des = self._frames(I_des)
+        des = self._frames(I_des) if I_des is not None else None   # None: the goal cached by set_goal()
         n = cur.shape[0]
-        if des.shape[0] != (1 if des_shared else n):
+        if des is not None and des.shape[0] != (1 if des_shared else n):
             raise VitvsError("I_des must hold one frame per pair (or one frame when des_shared)")
         z = None
         if Z is not None:
