@@ -652,6 +652,16 @@ def test_host_pointer_entry_point_matches_device_entry_point():
                                         p(depth), p(K), _lib.SELECT_DENSE, None, None, 0, p(v), p(st))
     assert rc == 0 and int(st[0]) == int(sd_[0])
     assert np.array_equal(v, vd.cpu().numpy()[0])
+    # the host-pointer goal cache: vitvs_set_goal, then I_des = NULL; equal to the device-pointer cached call
+    eng.set_goal(des)
+    vc_dev, _ = eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    vc_dev = vc_dev.cpu().numpy()[0].copy()
+    assert eng.lib.vitvs_set_goal(eng.handle, 1, p(np.ascontiguousarray(des))) == 0
+    v2 = np.zeros(6, np.float64)
+    rc = eng.lib.vitvs_compute_velocity(eng.handle, 1, p(np.ascontiguousarray(cur)), None, 0, p(depth), p(K), _lib.SELECT_DENSE,
+                                        None, None, 0, p(v2), p(st))
+    assert rc == 0 and np.array_equal(v2, vc_dev)
+    assert eng.lib.vitvs_set_goal(eng.handle, 2, p(np.ascontiguousarray(des))) < 0       # more goal frames than max_pairs
 
 
 # ----------------------------------------------------------------------------- host mirror of the reference interface
