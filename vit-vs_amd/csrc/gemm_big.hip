@@ -38,16 +38,30 @@ struct BigTile {
     static constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
     static constexpr int AH = (MT / 2) * 16, BH = (NT / 2) * 16;       // rows of one wave in a half slot
     static constexpr int A_ROWS = WGM * AH, B_ROWS = WGN * BH;        // rows of a half slot
-    static constexpr int LA = A_ROWS / 64, LB = B_ROWS / 64;          // LDS-DMA instructions per wave per slot (8 waves x 8 rows)
+    // LDS-DMA instructions per wave per slot (8 waves x 8 rows each).  A slot whose 8-row groups do not divide by the 8 waves
+    // (96 rows = 12 groups: the 192-column tile) is rounded up: the surplus instructions of the last round copy groups that
+    // another wave copies too (the same bytes to the same LDS address), so that every wave counts the same vmcnt
+    static constexpr int GA = A_ROWS / 8, GB = B_ROWS / 8, LA = (GA + 7) / 8, LB = (GB + 7) / 8;
     static constexpr int A_SLOT = A_ROWS * 128, B_SLOT = B_ROWS * 128;
     static constexpr int STAGE = 2 * A_SLOT + 2 * B_SLOT;
     static constexpr int RING = 2 * STAGE;
     static constexpr int WAVE_REGION = RING / 8;                      // epilogue image of one wave
     static constexpr int LDS_BYTES = RING;
     static_assert(WGM * WGN == 8 && MT % 2 == 0 && NT % 2 == 0, "8 waves, even tile counts");
-    static_assert(A_ROWS % 64 == 0 && B_ROWS % 64 == 0, "a half slot is a whole number of 8-row copies per wave");
+    static_assert(A_ROWS % 8 == 0 && B_ROWS % 8 == 0 && BH % 8 == 0 && AH % 8 == 0, "half slots are made of 8-row copies");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
+
+// 8-row group of a half slot that copy j of wave `wave` fills: G groups, L = ceil(G / 8) copies per wave.  Whole rounds keep
+// a wave's copies adjacent (wave * L + j); a partial last round wraps its surplus onto the round's own first groups.
+template <int G, int L>
+__device__ __forceinline__ int copy_group(int wave, int j) {
+    if constexpr (G == 8 * L) return wave * L + j;
+    else {
+        const int g = 8 * j + wave;                          // round j, one group per wave
+        return g < G ? g : g - (8 * L - G);                  // (96 rows: round 1 holds groups 8 .. 11, copied by waves 0-3 and 4-7)
+    }
+}
 
 // epilogue policies: what is added / applied to the fp32 sums and what is stored
 template <typename T>
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                const int rs = (wave * LA + j) * 8 + r8;                          // row inside the slot
+                const int rs = copy_group<Tile::GA, LA>(wave, j) * 8 + r8;        // row inside the slot
                 const int w_ = rs / Tile::AH, ml = rs - w_ * Tile::AH;
                 const int row = min(m0 + w_ * (MT * 16) + h * Tile::AH + ml, M - 1);
                 const int c = (lane & 7) ^ ((rs >> 1) & 7);
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
-                const int rs = (wave * LB + j) * 8 + r8;
+                const int rs = copy_group<Tile::GB, LB>(wave, j) * 8 + r8;
                 const int w_ = rs / Tile::BH, nl = rs - w_ * Tile::BH;
                 const int row = n0 + w_ * (NT * 16) + h * Tile::BH + nl;          // N is a multiple of BN
                 const int c = (lane & 7) ^ ((rs >> 1) & 7);
@@ -175,16 +189,18 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
         return smem + stage * Tile::STAGE + (kind < 2 ? kind * Tile::A_SLOT : 2 * Tile::A_SLOT + (kind - 2) * Tile::B_SLOT);
     };
     auto issue_a = [&](int h, int kt) {
-        unsigned char* dst = slot(kt & 1, h) + wave * LA * 1024;
+        unsigned char* dst = slot(kt & 1, h);
 #pragma unroll
         for (int j = 0; j < LA; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (offA[h][j] + (unsigned)kt * 128u)), (lds_ptr)(dst + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Ab + (offA[h][j] + (unsigned)kt * 128u)),
+                                             (lds_ptr)(dst + copy_group<Tile::GA, LA>(wave, j) * 1024), 16, 0, 0);
     };
     auto issue_b = [&](int h, int kt) {
-        unsigned char* dst = slot(kt & 1, 2 + h) + wave * LB * 1024;
+        unsigned char* dst = slot(kt & 1, 2 + h);
 #pragma unroll
         for (int j = 0; j < LB; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wb + (offB[h][j] + (unsigned)kt * 128u)), (lds_ptr)(dst + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(Wb + (offB[h][j] + (unsigned)kt * 128u)),
+                                             (lds_ptr)(dst + copy_group<Tile::GB, LB>(wave, j) * 1024), 16, 0, 0);
     };
 
     Epi epi;
@@ -294,11 +310,14 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     const int l15e = lane_e & 15, ge = lane_e >> 4;
     typedef typename Epi::Out O;
     constexpr int ES = (int)sizeof(O);
-    constexpr int ROW_BYTES = NT * 16 * ES;                        // 128 (16-bit, NT = 4), 256 (fp32, NT = 4), ...
+    // the wave's NT column tiles leave in groups of NTG whose row segment is a power-of-two number of 16-byte chunks
+    // (NT = 4: one group of 128 / 256 bytes per row; NT = 6, the 192-column tile: three groups of 64 / 128 bytes)
+    constexpr int NTG = (NT % 4 == 0) ? 4 : 2, NCG = NT / NTG;
+    constexpr int ROW_BYTES = NTG * 16 * ES;
     constexpr int CHUNKS = ROW_BYTES / 16;                         // 16-byte chunks per row (a power of two)
     constexpr int PASS_MT = (MT * 16 * ROW_BYTES <= Tile::WAVE_REGION) ? MT : MT / 2;
     static_assert(PASS_MT * 16 * ROW_BYTES <= Tile::WAVE_REGION, "epilogue image does not fit");
-    static_assert((CHUNKS & (CHUNKS - 1)) == 0 && CHUNKS <= 64, "row chunks");
+    static_assert((CHUNKS & (CHUNKS - 1)) == 0 && CHUNKS <= 64 && NT % NTG == 0, "row chunks");
     // per-column terms (bias): requested here rather than before the k-loop — 16 registers the loop cannot spare
     float4 col[NT];
 #pragma unroll
@@ -310,24 +329,26 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 #pragma unroll
     for (int pass = 0; pass < MT / PASS_MT; ++pass) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
+      for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+        for (int nl = 0; nl < NTG; ++nl)
 #pragma unroll
             for (int mp = 0; mp < PASS_MT; ++mp) {
-                const int mi = pass * PASS_MT + mp;
+                const int mi = pass * PASS_MT + mp, ni = cg * NTG + nl;
                 const f32x4 v = epi.apply(acc[ni][mi], col[ni]);
                 const int row = mp * 16 + l15e;
                 if constexpr (ES == 4) {
-                    const int chunk = ni * 4 + ge;
+                    const int chunk = nl * 4 + ge;
                     *reinterpret_cast<f32x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4)) = v;
                 } else {
-                    const int chunk = ni * 2 + (ge >> 1);
+                    const int chunk = nl * 2 + (ge >> 1);
                     const typename Vec16<O>::x4 h = {(O)v[0], (O)v[1], (O)v[2], (O)v[3]};
                     *reinterpret_cast<typename Vec16<O>::x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4) + (ge & 1) * 8) = h;
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image is this wave's own: no barrier
         __builtin_amdgcn_sched_barrier(0);
-        // whole rows back from the image, 8 reads in flight before their stores
+        // whole row segments back from the image, 8 reads in flight before their stores
         constexpr int NI = PASS_MT * 16 / ROWS_PER_INST, BATCH = NI < 8 ? NI : 8;
 #pragma unroll
         for (int b0 = 0; b0 < NI; b0 += BATCH) {
@@ -344,10 +365,12 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
                 // write-through (sc1): the rows leave for memory as they are stored instead of waiting, dirty in this XCD's
                 // L2, for the write-back at the kernel boundary (measured -3 ... -7 % on these launches: all of a tile's
                 // output is produced at its very end, so there is nothing for a write-back cache to merge)
-                if (m < M) store_out16<true>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0) + chunk * 16, rowv[i]);
+                if (m < M)
+                    store_out16<true>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0 + cg * NTG * 16) + chunk * 16, rowv[i]);
             }
         }
-        if (pass + 1 < MT / PASS_MT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (pass + 1 < MT / PASS_MT || cg + 1 < NCG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   }   // next tile of this workgroup
 }
@@ -355,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------------- launch side
 typedef BigTile<2, 4, 8, 4> Tile256x256;
 typedef BigTile<4, 2, 4, 4> Tile256x128;
+typedef BigTile<4, 2, 4, 6> Tile256x192;
 
 template <typename T, class Tile, class Epi>
 static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const float* bias, int M, int N, int K, int splits,
@@ -385,22 +409,16 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Which tile family for a many-row problem.  Measured on MI355X (tools/big_ops, random bf16 data, profiles/r02_big_ops.txt):
-// in its k-loop the 256x256 tile sustains ~1.5 PFLOP/s chip-wide, so what decides is how well the tile count fills the 256
-// CUs and the fixed cost per round (operand latency at the start, the output burst at the end: ~9 us at 6274 x 2304):
-//   * 120 .. 256 tiles of 256x256: one round, well filled                        -> 256x256
-//     (6274x2304: 24 us vs 27 (256x128) / 35 (gemm.hip); 3152x3072: 26 / 30 / 31; 2740x4096x1024: 31 / 36 / 36)
-//   * otherwise, >= 96 tiles of 256x128 (each CU walks its 1 .. 3 tiles)            -> 256x128
-//     (6274x3072: 46 vs 50 / 49; 6274x768x3072: 38 vs 55 / 46; 3152x2304: 16 vs 21 / 19; 788x3072: 15 vs 23 / 20)
-//   * fewer tiles than that (narrow layers at 3152 / 2740 rows): the 2-workgroups-per-CU tiles of gemm.hip win or tie.
-// Returns 0 (use gemm.hip), 256 or 128.
+// Which tile family for a many-row problem.  Measured on MI355X (tools/big_ops [mid], random bf16 data, profiles/r02_big_ops*.txt):
+// in its k-loop the 256x256 tile sustains ~1.5 PFLOP/s chip-wide, so what decides is how many tiles the busiest CU walks
+// (workgroups are persistent, one per CU) and the fixed cost per tile (operand latency at the start, the output burst at the
+// end: ~8 us at 6274 x 2304) — the rule below is that model with the relative tile costs measured.
+// Returns 0 (use gemm.hip), 256, 192 or 128.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
     // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
     // 11.9 us on 256 x 128 tiles); where they need a second round the 256-row tiles win from 64 tiles up (985 x 2304: 18.4 vs
-    // 11.9 us).  Between the two tile families of this file the busiest CU's share decides: a 256 x 128 tile costs 0.62 of a
-    // 256 x 256 one (half the k-loop, the same fixed cost), and a CU walks ceil(tiles / 256) of them
-    // (2364 x 3072: 120 tiles of 256 x 256 25.7 us, 240 of 256 x 128 17.4 us; 3152 x 3072: 156 -> 25.3 us, 312 -> 29.8 us).
+    // 11.9 us).  Between the tile families of this file the busiest CU's share decides (below).
     const long mt = (M + 63) / 64;
     for (int c : {128, 96, 64}) {
         if (partial && c != 64) continue;                         // the partial-sum kernels of gemm.hip are 64 wide
@@ -410,11 +428,15 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     if (N % 128 != 0 || N / 128 > 255) return 0;
     const long t128 = ny * (N / 128) * splits;
     if (t128 < (partial ? 96 : 64)) return 0;
-    if (N % 256 == 0) {
-        const long t256 = ny * (N / 256) * splits;
-        if ((double)((t256 + 255) / 256) < 0.62 * (double)((t128 + 255) / 256)) return 256;
-    }
-    return 128;
+    // relative cost of one tile (k-loop share + the same fixed cost): 256 x 256 = 1, 256 x 192 = 0.85, 256 x 128 = 0.62
+    // (3152 x 3072: 156 tiles of 256 x 256 25.1 us, 208 of 256 x 192 21.4 us, 312 of 256 x 128 29.6 us;
+    //  6274 x 3072: 300 -> 51.6, 400 -> 41.9, 600 -> 44.6 us; 2740 x 3072 x 1024: 132 -> 23.9, 176 -> 20.6, 264 -> 30.3 us)
+    auto rounds = [](long tiles) { return (double)((tiles + 255) / 256); };
+    int best = 128;
+    double cost = 0.62 * rounds(t128);
+    if (N % 192 == 0 && 0.85 * rounds(ny * (N / 192) * splits) < cost) { best = 192; cost = 0.85 * rounds(ny * (N / 192) * splits); }
+    if (N % 256 == 0 && rounds(ny * (N / 256) * splits) < cost) best = 256;
+    return best;
 }
 
 template <typename T>
@@ -422,9 +444,11 @@ static int launch_big_t(int bn, const T* A, const T* W, const float* bias, void*
                         bool partial, hipStream_t stream) {
     if (partial) {
         if (bn == 256) return launch_big_one<T, Tile256x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+        if (bn == 192) return launch_big_one<T, Tile256x192, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
         return launch_big_one<T, Tile256x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
     }
     if (bn == 256) return launch_big_one<T, Tile256x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+    if (bn == 192) return launch_big_one<T, Tile256x192, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
     return launch_big_one<T, Tile256x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
 }
 
