@@ -23,8 +23,8 @@ VITVS_API int vitvs_op_linear(int32_t precision, const void* A, const void* W, c
                     int32_t N, int32_t K, int32_t gelu, void* stream);
 /* The same operator on a chosen tile family (the library picks one by itself in vitvs_op_linear): variant 0 = the
  * library's choice, 1 = the 64/128-row tiles of gemm.hip as that file picks them, 2 = its 128 x 128 tiles whatever the shape
- * (16-bit precisions, N % 128 == 0), 256 / 192 / 128 = the 256-row tiles of gemm_big.hip with that column width (16-bit
- * precisions, N % variant == 0, K >= 128).  For the parity tests of both families on one shape and for
+ * (16-bit precisions, N % 128 == 0), 256 / 192 / 128 = the 256-row tiles of gemm_big.hip with that column width, 1192 = its
+ * 192 x 128 tile (16-bit precisions, N % width == 0, K >= 128).  For the parity tests of both families on one shape and for
  * tools/big_ops.  slices > 0 selects the split-K form: out = fp32 part[slices][M][N], bias / gelu ignored. */
 VITVS_API int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, const void* W, const float* bias,
                             void* out, int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t slices, void* stream);

@@ -107,7 +107,8 @@ def test_linear_tile_plan_of_the_library():
     assert plan(b, 6274, 3072, 768) == (256, 192, 0)         # 400 tiles in two rounds beat 600 of 256 x 128 in three
     assert plan(b, 2740, 3072, 1024) == (256, 192, 0)        # ViT-L/14 518
     assert plan(b, 2740, 4096, 1024) == (256, 256, 0)
-    assert plan(b, 2740, 1024, 4096, 2) == (256, 128, 0)
+    assert plan(b, 2740, 1024, 4096, 2) == (192, 128, 0)     # 240 tiles of 192 x 128 in one round against 176 of 256 x 128
+    assert plan(b, 6274, 768, 3072, 1) == (192, 128, 0)
     assert plan(_lib.F32, 6274, 3072, 768) == (128, 128, 1)  # fp32 never takes the 256-row kernels
     t = (ctypes.c_int32 * 3)()
     assert lib.vitvs_op_linear_tile(b, 394, 768, 3072, 5, t) != 0   # 3072 is not a multiple of 5 k-tiles

@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * s.M * s.N * s.K;
         printf("%-20s %6d %6d %6d |", s.name, s.M, s.N, s.K);
         if (s.slices < 0) printf(" %d slice(s) |", sl);
-        for (int variant : {0, 1, 256, 128, 2, 192}) {
+        for (int variant : {0, 1, 256, 128, 2, 192, 1192}) {
             int turn = 0;
             const double us = run(st, fast ? 20 : 60, [&] {
                 return vitvs_op_linear_variant(VITVS_BF16, variant, A, Wt[(turn++) % nsets], bias, out, s.M, s.N, s.K, s.gelu, sl, st);

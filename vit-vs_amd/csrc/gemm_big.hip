@@ -379,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 typedef BigTile<2, 4, 8, 4> Tile256x256;
 typedef BigTile<4, 2, 4, 4> Tile256x128;
 typedef BigTile<4, 2, 4, 6> Tile256x192;
+typedef BigTile<2, 4, 6, 2> Tile192x128;      // selected as width code 1192 (192 rows x 128 columns)
 
 template <typename T, class Tile, class Epi>
 static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const float* bias, int M, int N, int K, int splits,
@@ -413,7 +414,7 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
 // in its k-loop the 256x256 tile sustains ~1.5 PFLOP/s chip-wide, so what decides is how many tiles the busiest CU walks
 // (workgroups are persistent, one per CU) and the fixed cost per tile (operand latency at the start, the output burst at the
 // end: ~8 us at 6274 x 2304) — the rule below is that model with the relative tile costs measured.
-// Returns 0 (use gemm.hip), 256, 192 or 128.
+// Returns 0 (use gemm.hip), the column width 256, 192 or 128 of a 256-row tile, or 1192 for the 192 x 128 tile.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
     // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
@@ -435,13 +436,23 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     int best = 128;
     double cost = 0.62 * rounds(t128);
     if (N % 192 == 0 && 0.85 * rounds(ny * (N / 192) * splits) < cost) { best = 192; cost = 0.85 * rounds(ny * (N / 192) * splits); }
-    if (N % 256 == 0 && rounds(ny * (N / 256) * splits) < cost) best = 256;
+    if (N % 256 == 0 && rounds(ny * (N / 256) * splits) < cost) { best = 256; cost = rounds(ny * (N / 256) * splits); }
+    // 192-row x 128-column tiles (code 1192): more, smaller tiles for the narrow layers — 6274 x 768 x 3072: 198 tiles 34.8 us
+    // against 150 of 256 x 128 37.4 us; 2740 x 1024 x 4096 in 2 K slices: 240 tiles 25.7 us against 176 -> 27.8 us; a tile costs
+    // 0.58 (its waves' 96 x 32 sub-tiles read more LDS per FLOP than 64 x 64 ones, so it only pays while it stays in one round
+    // where 256 x 128 leaves CUs idle: 3152 x 768 x 3072 in 3 slices, 306 tiles, 27.5 us against 234 -> 19.3 us)
+    const long t1192 = (long)((M + 191) / 192) * (N / 128) * splits;
+    if (partial && 0.58 * rounds(t1192) < cost) best = 1192;      // (measured on the narrow partial-sum layers only)
     return best;
 }
 
 template <typename T>
 static int launch_big_t(int bn, const T* A, const T* W, const float* bias, void* out, int M, int N, int K, int splits, int gelu,
                         bool partial, hipStream_t stream) {
+    if (bn == 1192) {
+        if (partial) return launch_big_one<T, Tile192x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+        return launch_big_one<T, Tile192x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+    }
     if (partial) {
         if (bn == 256) return launch_big_one<T, Tile256x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
         if (bn == 192) return launch_big_one<T, Tile256x192, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);

@@ -81,7 +81,8 @@ int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const floa
                        int n_img, int T, int D, int Kp, hipStream_t stream);
 
 // ---- gemm_big.hip: 256-row tiles for many-row problems (16-bit operands) --------------------------------
-// big_tile_width: 0 = not applicable (use the tiles of gemm.hip), else the column-tile width (256, 192 or 128) to pass on.
+// big_tile_width: 0 = not applicable (use the tiles of gemm.hip), else the tile code to pass on: the column width 256, 192 or 128 of a
+// 256-row tile, or 1192 = 192 rows x 128 columns.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial);
 // (BM, BN, KG) of the kernel launch_linear (partial = false, splits = 1) / launch_linear_partial picks; KG = 0: 256-row tiles
 int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial, int out[3]);
