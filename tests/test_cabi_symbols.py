@@ -96,8 +96,8 @@ def test_linear_tile_plan_of_the_library():
     assert plan(b, 394, 2304, 768) == (64, 64, 2)
     assert plan(b, 394, 768, 3072, 3) == (64, 64, 2)
     assert plan(b, 788, 2304, 768) == (64, 128, 2)           # two pairs: still one round of 64-row tiles
-    assert plan(b, 788, 3072, 768) == (256, 128, 0)
-    assert plan(b, 985, 2304, 768) == (256, 128, 0)          # rotation search (5 images): a second round of 64-row tiles loses
+    assert plan(b, 788, 3072, 768) == (192, 128, 0)          # 120 tiles of 192 x 128 against 96 of 256 x 128
+    assert plan(b, 985, 2304, 768) == (192, 128, 0)          # rotation search (5 images): a second round of 64-row tiles loses
     assert plan(b, 2364, 3072, 768) == (256, 128, 0)         # 120 tiles of 256 x 256 would leave half the CUs idle
     assert plan(b, 3152, 3072, 768) == (256, 192, 0)         # 8 pairs: 208 tiles of 256 x 192 in one round beat 156 of 256 x 256
     assert plan(b, 3152, 2304, 768) == (256, 128, 0)
@@ -106,7 +106,7 @@ def test_linear_tile_plan_of_the_library():
     assert plan(b, 6274, 2304, 768) == (256, 256, 0)         # ViT-B/8 448
     assert plan(b, 6274, 3072, 768) == (256, 192, 0)         # 400 tiles in two rounds beat 600 of 256 x 128 in three
     assert plan(b, 2740, 3072, 1024) == (256, 192, 0)        # ViT-L/14 518
-    assert plan(b, 2740, 4096, 1024) == (256, 256, 0)
+    assert plan(b, 2740, 4096, 1024) == (192, 256, 0)        # 240 tiles against 176 of 256 x 256
     assert plan(b, 2740, 1024, 4096, 2) == (192, 128, 0)     # 240 tiles of 192 x 128 in one round against 176 of 256 x 128
     assert plan(b, 6274, 768, 3072, 1) == (192, 128, 0)
     assert plan(_lib.F32, 6274, 3072, 768) == (128, 128, 1)  # fp32 never takes the 256-row kernels

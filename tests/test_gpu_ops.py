@@ -188,14 +188,14 @@ def test_split_k_pair(lib, name, prec, dtype, tol, M, D, K, use_ls, use_ln):
 
 
 @pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
-@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1, 2])
+@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1256, 1, 2])
 @pytest.mark.parametrize("M,N,K,gelu", [(6274, 2304, 768, 0), (2740, 1024, 1024, 1), (1025, 256, 128, 0), (3152, 768, 3072, 1),
                                         (300, 512, 192, 0), (1025, 384, 128, 1), (3152, 3072, 768, 1)])
 def test_linear_tile_families_agree_with_the_reference(lib, name, prec, dtype, tol, variant, M, N, K, gelu):
     """The 256-row tiles of gemm_big.hip (both column widths) and the tiles of gemm.hip on the same shapes: ragged last
     row tile (M % 256 != 0), the shortest k-loop the big kernel accepts (K = 128: prologue + two tail k-tiles only), odd
     and even k-tile counts, and a row count below one tile."""
-    if variant >= 128 and N % (128 if variant == 1192 else variant) != 0:
+    if variant >= 128 and N % {1192: 128, 1256: 256}.get(variant, variant) != 0:
         pytest.skip("this tile width does not divide N")
     g = torch.Generator().manual_seed(M * 3 + N + K)
     A = _mk((M, K), g).to(dtype)
@@ -214,11 +214,11 @@ def test_linear_tile_families_agree_with_the_reference(lib, name, prec, dtype, t
     assert _rel(out[:M].cpu(), ref) <= tol
 
 
-@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1, 2])
+@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1256, 1, 2])
 @pytest.mark.parametrize("M,N,K,slices", [(6274, 768, 3072, 3), (2740, 1024, 1024, 2), (1500, 256, 768, 1), (1500, 384, 768, 2)])
 def test_linear_partial_tile_families(lib, variant, M, N, K, slices):
     """Split-K partial sums from both tile families: slice z holds exactly the products of its K range (fp32)."""
-    if variant >= 128 and N % (128 if variant == 1192 else variant) != 0:
+    if variant >= 128 and N % {1192: 128, 1256: 256}.get(variant, variant) != 0:
         pytest.skip("this tile width does not divide N")
     g = torch.Generator().manual_seed(M + N + K + slices)
     A = _mk((M, K), g).to(torch.bfloat16)

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
         {"1576 fc2  3 slices", 1576, 768, 3072, 0, 3}, {"1576 fc2  4 slices", 1576, 768, 3072, 0, 4}, {"1576 fc2  6 slices", 1576, 768, 3072, 0, 6},
     };
     const int nsets = 4;
-    printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, 64-row tiles, 256x256, 256x128, 128x128, 256x192");
+    printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, 64-row tiles, 256x256, 256x128, 128x128, 256x192, 192x128, 192x256");
     // "occ": attention only, on a probe build of the library, with the workgroups per CU limited through their LDS size
     const bool occ = argc > 1 && !strcmp(argv[1], "occ");
     const bool attn_only = occ || (argc > 1 && (!strcmp(argv[1], "attn") || !strcmp(argv[1], "attnmid")));
@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * s.M * s.N * s.K;
         printf("%-20s %6d %6d %6d |", s.name, s.M, s.N, s.K);
         if (s.slices < 0) printf(" %d slice(s) |", sl);
-        for (int variant : {0, 1, 256, 128, 2, 192, 1192}) {
+        for (int variant : {0, 1, 256, 128, 2, 192, 1192, 1256}) {
             int turn = 0;
             const double us = run(st, fast ? 20 : 60, [&] {
                 return vitvs_op_linear_variant(VITVS_BF16, variant, A, Wt[(turn++) % nsets], bias, out, s.M, s.N, s.K, s.gelu, sl, st);

@@ -915,6 +915,7 @@ int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, c
         return slices > 0 ? launch_linear_partial_classic(p, A, W, (float*)out, M, N, K, slices, st)
                           : launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, st);
     if (variant == 2) return launch_linear_128(p, A, W, bias, out, M, N, K, gelu, slices > 0 ? slices : 1, slices > 0, st);
+    if (variant == 1256) return (N % 256 || K % 64) ? -2 : launch_linear_big(p, 1256, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
     if (variant == 1192) return (N % 128 || K % 64) ? -2 : launch_linear_big(p, 1192, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
     if ((variant != 256 && variant != 192 && variant != 128) || N % variant != 0 || K % 64 != 0) return -2;
     return launch_linear_big(p, variant, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);

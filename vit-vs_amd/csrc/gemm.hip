@@ -363,7 +363,7 @@ int launch_linear_partial_classic(Precision p, const void* A, const void* W, flo
 int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial, int out[3]) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0 || (!partial && splits != 1)) return -2;
     if (const int bn = big_tile_width(p, M, N, K, splits, partial)) {
-        out[0] = bn == 1192 ? 192 : 256; out[1] = bn == 1192 ? 128 : bn; out[2] = 0;
+        out[0] = bn > 1000 ? 192 : 256; out[1] = bn > 1000 ? bn - 1000 - 64 * (bn == 1192) : bn; out[2] = 0;   // 1192 -> 128, 1256 -> 256
         return 0;
     }
     if (big_problem(M, N, splits)) { out[0] = 128; out[1] = 128; out[2] = 1; return 0; }

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image is this wave's own: no barrier
         __builtin_amdgcn_sched_barrier(0);
         // whole row segments back from the image, 8 reads in flight before their stores
-        constexpr int NI = PASS_MT * 16 / ROWS_PER_INST, BATCH = NI < 8 ? NI : 8;
+        // (the batch must divide the row-instruction count: 96 rows x 128 bytes are 12 instructions, read 6 + 6, not 8 + 8)
+        constexpr int NI = PASS_MT * 16 / ROWS_PER_INST;
+        constexpr int BATCH = NI < 8 ? NI : (NI % 8 == 0 ? 8 : (NI % 6 == 0 ? 6 : (NI % 4 == 0 ? 4 : (NI % 2 == 0 ? 2 : 1))));
+        static_assert(NI % BATCH == 0 && (PASS_MT * 16) % ROWS_PER_INST == 0, "epilogue batches cover the image exactly");
 #pragma unroll
         for (int b0 = 0; b0 < NI; b0 += BATCH) {
             u32x4 rowv[BATCH];
@@ -380,6 +383,7 @@ typedef BigTile<2, 4, 8, 4> Tile256x256;
 typedef BigTile<4, 2, 4, 4> Tile256x128;
 typedef BigTile<4, 2, 4, 6> Tile256x192;
 typedef BigTile<2, 4, 6, 2> Tile192x128;      // selected as width code 1192 (192 rows x 128 columns)
+typedef BigTile<2, 4, 6, 4> Tile192x256;      // width code 1256 (192 rows x 256 columns)
 
 template <typename T, class Tile, class Epi>
 static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const float* bias, int M, int N, int K, int splits,
@@ -414,7 +418,7 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
 // in its k-loop the 256x256 tile sustains ~1.5 PFLOP/s chip-wide, so what decides is how many tiles the busiest CU walks
 // (workgroups are persistent, one per CU) and the fixed cost per tile (operand latency at the start, the output burst at the
 // end: ~8 us at 6274 x 2304) — the rule below is that model with the relative tile costs measured.
-// Returns 0 (use gemm.hip), the column width 256, 192 or 128 of a 256-row tile, or 1192 for the 192 x 128 tile.
+// Returns 0 (use gemm.hip), the column width 256, 192 or 128 of a 256-row tile, or 1192 / 1256 for the 192 x 128 / 192 x 256 tile.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
     // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
@@ -442,13 +446,22 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     // 0.58 (its waves' 96 x 32 sub-tiles read more LDS per FLOP than 64 x 64 ones, so it only pays while it stays in one round
     // where 256 x 128 leaves CUs idle: 3152 x 768 x 3072 in 3 slices, 306 tiles, 27.5 us against 234 -> 19.3 us)
     const long t1192 = (long)((M + 191) / 192) * (N / 128) * splits;
-    if (partial && 0.58 * rounds(t1192) < cost) best = 1192;      // (measured on the narrow partial-sum layers only)
+    // (also ahead on wide layers while in one round: 788 .. 1576 x 3072: 13.2 .. 14.1 us against 14.8 .. 15.7; two rounds from
+    //  1970 rows on: 24.8 against 16.2 us)
+    if (0.58 * rounds(t1192) < cost) { best = 1192; cost = 0.58 * rounds(t1192); }
+    // 192 x 256 (code 1256), priced 0.9: 2740 x 4096 x 1024 (N is not a multiple of 192): 240 tiles 27.6 us against 176 of
+    // 256 x 256 -> 29.8 us; level with 256 x 192 where that applies (3152 x 3072: 21.7 / 21.6 us)
+    if (N % 256 == 0 && 0.9 * rounds((long)((M + 191) / 192) * (N / 256) * splits) < cost) best = 1256;
     return best;
 }
 
 template <typename T>
 static int launch_big_t(int bn, const T* A, const T* W, const float* bias, void* out, int M, int N, int K, int splits, int gelu,
                         bool partial, hipStream_t stream) {
+    if (bn == 1256) {
+        if (partial) return launch_big_one<T, Tile192x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+        return launch_big_one<T, Tile192x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+    }
     if (bn == 1192) {
         if (partial) return launch_big_one<T, Tile192x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
         return launch_big_one<T, Tile192x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
