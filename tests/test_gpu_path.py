@@ -586,13 +586,21 @@ def test_rotation_compensation_scores_match_the_reference():
         assert abs(own[i] - float(blob[f"view{i}/score"])) <= 0.03
 
 
-def test_graph_replay_matches_eager(monkeypatch):
+@pytest.mark.parametrize("many_tokens", [False, True])
+def test_graph_replay_matches_eager(monkeypatch, many_tokens):
     """VITVS_GRAPH=1 (read at vitvs_create): the update replayed as one captured hipGraph gives bit-identical results,
-    also when the visiting order changes from update to update (it is not part of the graph's key)."""
-    cfg = config.baseline_config("vits16_224")
-    sd = weights.synthetic_state_dict(cfg, 0)
-    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vits16_224"])
+    also when the visiting order changes from update to update (it is not part of the graph's key).  The many-token case
+    (1024 tokens) replays the key-split attention (tickets reset by the kernel itself) and the f16 Gram with its split launch."""
+    if many_tokens:
+        cfg = _tiny_cfg(False, img=512)
+        sd = weights.synthetic_state_dict(cfg, 5)
+        params = config.ServoParams(dino_input_size=512, use_feature_binning=False)
+        des, cur = synth.frame_pair(512, 20250801)
+    else:
+        cfg = config.baseline_config("vits16_224")
+        sd = weights.synthetic_state_dict(cfg, 0)
+        params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+        des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vits16_224"])
     dev = torch.device("cuda")
     I_cur, I_des = torch.from_numpy(cur[None]).to(dev), torch.from_numpy(des[None]).to(dev)
     Z = torch.from_numpy(synth.depth_pattern()[None]).to(dev)
