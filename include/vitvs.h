@@ -176,6 +176,9 @@ VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t*
  *   s_uv int32 [n_pairs][max_rows][4] = u*, v*, u, v ; feat double [n_pairs][max_rows][4] = Z, x, y, sim
  *        (feat[..][3] over the first n_matched rows is the reference's sim_selected_12, vitvs_v2.py:523, 1167-1174)
  *   L double [n_pairs][7][2*max_rows] column-major: 6 columns of L_e then e.
+ * A call's law uses n_feature_rows = info[1] feature pairs (num_pairs, or every candidate for DENSE); rows of
+ * `selected` / `s_uv` / `feat` from n_feature_rows on, and rows of `L` from 2 * n_feature_rows on, are returned as
+ * -1 / 0 / 0 / 0 whatever an earlier, larger call left in the workspace.
  * Any pointer may be NULL. */
 VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,
                        int32_t* selected, int32_t* s_uv, double* feat, double* L);

@@ -1,0 +1,143 @@
+"""Closed loop on the GPU: ``ServoLoop(servo.Controller(Engine))`` driving a simulated camera over a textured plane
+(tests/planar_sim.py).  SURVEY.md §8(f)4: the reference's ``run()`` (vitvs_v2.py:702-819) calls ``ibvs()`` hundreds of
+times with changing frames, and ``is_visual_servoing_done`` (:345-421) decides when to stop; tests/test_servo_loop.py pins
+the loop's bookkeeping against the reference on scripted episodes with a stand-in controller — here the real controller,
+the real engine and the device path run together:
+
+  (i)   per update, the raw v_c of the device path equals the CPU oracle's on the same camera frames and the same RNG
+        draw (fp32; <= 1e-9 relative L2, bar 1e-4), with the reference's own selection procedure;
+  (ii)  from a 5 cm / 5 degree offset the loop drives the feature error down by >= 90 % and ends through
+        ``is_visual_servoing_done`` (fp32 and bf16), without a divergence abort, the pose error shrinking to the
+        patch-quantisation dead zone (features are patch centres: once every match is the identity, e = 0);
+  (iii) over >= 300 consecutive device updates the controller's EMA state, failure counter and
+        ``velocity_vector_history`` equal a host replay of the recorded raw twists, bit for bit.
+
+The scene's texture is smooth at the patch scale (synth.texture at 128 px over 1.6 m): with the synthetic (untrained)
+weights nearest-neighbour matches of fine texture contain gross outliers a trained DINOv2 would not produce, and the
+least-squares law has no outlier rejection — as in the reference.
+"""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import _lib, config, loop, servo, synth, weights
+from oracle import servo_ref as sr
+from oracle import vit_ref
+from planar_sim import CameraSim, PlanarScene, rodrigues
+
+pytestmark = pytest.mark.gpu
+
+KEY = "vits16_224"
+DT = 0.5            # seconds of simulated motion per update (lambda * dt = 0.015: e-folding in 67 updates)
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _setup(precision, selection):
+    from vitvs_amd.engine import Engine
+    cfg = config.baseline_config(KEY)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    eng = Engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    scene = PlanarScene(synth.texture(128, 11), 1.6 / 128, params, plane_z=0.61, device="cuda")
+    goal_rgb, _ = scene.render(np.eye(3), np.zeros(3))
+    ctl = servo.Controller(eng, goal_image=goal_rgb, selection=selection)
+    axis = np.array([0.3, -0.4, 0.85])
+    axis /= np.linalg.norm(axis)
+    direction = np.array([0.6, -0.5, 0.6])
+    direction /= np.linalg.norm(direction)
+    sim = CameraSim(scene, ctl, rodrigues(axis * np.deg2rad(5.0)), direction * 0.05, DT)
+    return cfg, params, sd, eng, scene, ctl, sim, goal_rgb
+
+
+def _oracle_tokens(cfg, sd, rgb_cam):
+    small = np.asarray(Image.fromarray(rgb_cam).resize((cfg.img_size, cfg.img_size)))     # vitvs_v2.py:474-475
+    return vit_ref.block_tokens(sd, small[None], patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                mean=cfg.mean, std=cfg.std)[0, 1:]
+
+
+def test_closed_loop_raw_twist_equals_the_oracle_update_by_update():
+    cfg, params, sd, eng, scene, ctl, sim, goal_rgb = _setup("fp32", "reference")
+    goal_tokens = _oracle_tokens(cfg, sd, goal_rgb)
+    ema = sr.Ema(params.ema_alpha)
+    torch.manual_seed(121)                                            # the reference seeds once, vitvs_v2.py:1397
+    identical = 0
+    n_updates = 12
+    for it in range(n_updates):
+        sim.sense()
+        rng_before = torch.get_rng_state()
+        ctl.ibvs()                                                    # device path, the reference's draw on torch's global RNG
+        assert ctl.last_status == 0 and ctl.v_c is not None
+        det = eng.last_details(1)
+        gen = torch.Generator()
+        gen.set_state(rng_before)
+        out = sr.servo_update(goal_tokens, _oracle_tokens(cfg, sd, sim.last_rgb), sim.last_depth, num_pairs=params.num_pairs,
+                              input_size=cfg.img_size, u_max=params.u_max, v_max=params.v_max, fx=params.f_x, fy=params.f_y,
+                              lam=params.lambda_, generator=gen, exact_order=False)
+        assert out["status"] == "ok"
+        n1, n2 = out["corr"]["nn_1"].numpy(), out["corr"]["nn_2"].numpy()
+        if np.array_equal(det["nn_1"][0], n1) and np.array_equal(det["nn_2"][0], n2):
+            identical += 1
+            assert np.array_equal(det["selected"][0, :params.num_pairs], out["corr"]["selected"].numpy())   # the same draw
+            assert np.array_equal(det["s_uv"][0, :params.num_pairs, 2:], out["s_uv"])
+            assert _rel_l2(ctl._raw_v, out["v_c"]) <= 1e-9
+            assert _rel_l2(ctl.v_c, ema.update(out["v_c"])) <= 1e-9
+        else:       # an arg-max on the other side of a numerical tie changes the candidate list and hence the draw:
+            S = sr.cosine_matrix(goal_tokens, _oracle_tokens(cfg, sd, sim.last_rgb), exact_order=False).numpy()
+            for got, ref, M in ((det["nn_1"][0], n1, S), (det["nn_2"][0], n2, S.T)):
+                bad = np.nonzero(got != ref)[0]
+                assert all(M[i, ref[i]] - M[i, got[i]] <= 2e-5 for i in bad)
+            ema.update(ctl._raw_v)
+        lin, ang = ctl.publish_twist()
+        sim.apply_twist(lin, ang)
+    print(f"closed loop fp32: {identical} of {n_updates} updates with arg-max tables identical to the oracle's "
+          f"(draw, pixel features, raw and smoothed v_c then equal the oracle's)")
+    assert identical >= n_updates - 2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_closed_loop_converges_and_keeps_its_state(precision):
+    cfg, params, sd, eng, scene, ctl, sim, goal_rgb = _setup(precision, "order")
+    raw, status, feat_err = [], [], []
+    real_ibvs = ctl.ibvs
+
+    def recording_ibvs():
+        real_ibvs()
+        raw.append(np.array(ctl._raw_v, np.float64).reshape(6).copy())
+        status.append(ctl.last_status)
+        det = eng.last_details(1)
+        k = params.num_pairs
+        feat_err.append(float(np.linalg.norm(det["L"][0, 6, :2 * k])))
+    ctl.ibvs = recording_ibvs
+    logs = []
+    sl = loop.ServoLoop(ctl, np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]), get_pose=sim.get_pose, apply_twist=sim.apply_twist,
+                        sense=sim.sense, max_iterations=360, log=logs.append)
+    res = sl.run()
+    # (ii) ended by the convergence monitor at the iteration cap, not by an abort or an exception
+    assert res is not None and res.iteration_count == 360 and "Maximum iterations reached" in logs
+    assert not any("Aborting" in m or "Error" in m for m in logs)
+    assert all(s in (0, 2) for s in status) and ctl.feature_failure_count == 0
+    start, end = float(np.mean(feat_err[:5])), float(np.mean(feat_err[-60:]))
+    p0, r0 = sl.initial_error_translation, sl.initial_error_rotation
+    print(f"closed loop {precision}: feature error {start:.4f} -> {end:.4f} ({100 * (1 - end / start):.1f} % down), pose error "
+          f"{p0:.2f} cm / {r0:.2f} deg -> {res.position_error:.2f} cm / {res.orientation_error:.2f} deg, "
+          f"lowest {res.lowest_position_error:.2f} cm / {res.lowest_orientation_error:.2f} deg")
+    assert abs(p0 - 5.0) < 1e-9 and abs(r0 - 5.0) < 1e-6
+    assert end <= 0.1 * start                                           # >= 90 % of the feature error gone
+    assert res.position_error <= 0.8 * p0 and res.orientation_error <= 0.8 * r0
+    assert res.position_error <= 2 * p0                                 # never near the divergence abort
+    # (iii) >= 300 consecutive device updates: EMA state, history and the run's arrays against a host replay
+    assert len(raw) == 360 and sim.frames == 360
+    ema = sr.Ema(params.ema_alpha)
+    replay = [ema.update(v) for v in raw]
+    assert np.array_equal(np.array(ctl.velocity_vector_history), np.array(replay[-200:]))   # capped at 200, config.yaml:37
+    assert np.array_equal(ctl.v_c, replay[-1]) and np.array_equal(np.array(ctl.ema_velocities, np.float64), replay[-1])
+    assert np.array_equal(res.average_velocities, np.array([np.mean(np.abs(v)) for v in replay]))
+    lin = np.array([sr.twist_remap(v, params.max_velocity)[0] for v in replay])
+    assert np.array_equal(np.stack([res.applied_velocity_x, res.applied_velocity_y, res.applied_velocity_z], 1), lin)
+    assert len(res.position_history) == 360

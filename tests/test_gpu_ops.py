@@ -250,3 +250,31 @@ def test_long_attention_rescale_branch_is_forced(lib):
             assert lib.vitvs_op_attention(prec, _p(qd), _p(out), 1, N, 1, _stream()) == 0
             torch.cuda.synchronize()
             assert _rel(out.cpu(), _attention_ref(q, 1, N, 1)) <= tol
+
+
+def test_split_attention_on_two_streams_at_once(lib):
+    """The key-split attention keeps per-launch state (partial softmax states, tickets) in a workspace.  The operator hook's
+    workspace is per (device, stream): two streams running split launches concurrently on different inputs must each get
+    the result they get alone (bit for bit), launch after launch."""
+    n_img, N, H = 1, 1370, 16                                   # 352 query blocks -> keys split in two ranges
+    D = H * 64
+    g = torch.Generator().manual_seed(99)
+    qa = _mk((n_img * N, 3 * D), g).to(torch.bfloat16).cuda()
+    qb = _mk((n_img * N, 3 * D), g, 2.0).to(torch.bfloat16).cuda()
+    alone = []
+    for q in (qa, qb):
+        out = torch.empty((n_img * N, D), dtype=torch.bfloat16, device="cuda")
+        assert lib.vitvs_op_attention(_lib.BF16, _p(q), _p(out), n_img, N, H, _stream()) == 0
+        torch.cuda.synchronize()
+        alone.append(out.clone())
+    assert _rel(alone[0].cpu(), _attention_ref(qa.cpu(), n_img, N, H)) <= 2e-2
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a = [torch.empty_like(alone[0]) for _ in range(6)]
+    outs_b = [torch.empty_like(alone[1]) for _ in range(6)]
+    torch.cuda.synchronize()
+    for i in range(6):                                          # interleaved enqueue: the launches of the two streams overlap
+        assert lib.vitvs_op_attention(_lib.BF16, _p(qa), _p(outs_a[i]), n_img, N, H, C.c_void_p(sa.cuda_stream)) == 0
+        assert lib.vitvs_op_attention(_lib.BF16, _p(qb), _p(outs_b[i]), n_img, N, H, C.c_void_p(sb.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(outs_a[i], alone[0]) and torch.equal(outs_b[i], alone[1])

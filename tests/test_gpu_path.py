@@ -315,8 +315,14 @@ def test_cached_shared_goal_batch_matches_the_recomputing_call(precision):
         a2 = float((det["nn_2"][b] == det_ref["nn_2"][b]).mean())
         assert a1 >= 0.99 and a2 >= 0.99, (b, a1, a2)
         np.testing.assert_allclose(det["sim_1"][b], det_ref["sim_1"][b], rtol=0, atol=2e-5 if precision == "fp32" else 2e-2)
-        if np.array_equal(det["nn_1"][b], det_ref["nn_1"][b]) and np.array_equal(det["nn_2"][b], det_ref["nn_2"][b]):
-            assert _rel_l2(v[b].cpu().numpy(), v_ref[b].cpu().numpy()) <= 1e-9
+        # DENSE selection: v_c is the oracle's law on the call's OWN tables, checked for both calls (never skipped); equal
+        # tables then give equal twists
+        for dd, vv in ((det, v), (det_ref, v_ref)):
+            n1, n2 = dd["nn_1"][b].astype(np.int64), dd["nn_2"][b].astype(np.int64)
+            mutual = np.nonzero(n2[n1] == np.arange(cfg.tokens))[0]
+            assert 4 <= len(mutual) < cfg.tokens
+            want = _law_on(cfg, params, mutual, n1[mutual], depth[b], len(mutual))["v_c"]
+            assert _rel_l2(vv[b].cpu().numpy(), want) <= 1e-9
 
 
 def _tie_tolerant_agreement(got, ref_idx, sim_ref_rows, tol):
@@ -364,11 +370,34 @@ def test_compute_velocity_fp32_many_tokens(key):
     assert _rel_l2(v, want) <= 1e-9 <= VC_TOL
 
 
-# 16-bit operand modes (the headline dtype): arg-max agreement with the fp32 oracle and v_c, over the 8 accepted
-# ViT-B/16 pairs of the rig fixture.  v_c is a function of INTEGER pixel features, so in these modes it is either the
-# oracle's to fp64 round-off (same selected tokens, same matches) or a different, equally valid feature draw; the test
-# asserts the former whenever the selected tokens and their matches agree, and reports how often they do.
-MODE_BARS = {"bf16": dict(agree=0.90, sim_atol=2e-2), "fp16": dict(agree=0.97, sim_atol=3e-3)}
+# 16-bit operand modes (the headline dtype): over the 8 accepted ViT-B/16 pairs of the rig fixture.
+#   * arg-max tables against the fp32 oracle: per-pair agreement at least `agree`, and EVERY disagreement is a near-tie of the
+#     oracle's own similarity matrix (the two candidates differ by at most `tie` there, the mode's similarity error);
+#   * v_c is a function of INTEGER pixel features, so it is checked to fp64 round-off on every pair, never skipped: against
+#     the fixture's v_c where the device's matches at the drawn tokens are the fixture's, else against the oracle's law
+#     evaluated on the device's own matches;
+#   * the ORDER selection is exact given the device's own tables (first num_pairs mutual NNs met in the visiting order), and
+#     `same_draw` counts the pairs whose draw and matches equal the ones the fp32 oracle's tables give.
+# DESIGN.md §3 quotes these numbers; they are assertions here.
+MODE_BARS = {"bf16": dict(agree1=0.995, agree2=0.99, tie=2e-2, sim_atol=2e-2, same_fixture=8, same_draw=8),
+             "fp16": dict(agree1=1.0, agree2=1.0, tie=3e-3, sim_atol=3e-3, same_fixture=8, same_draw=8)}
+
+
+def _law_on(cfg, params, ids, matches, depth, rows):
+    """The oracle's control law (calculate_uv ... pinv) for desired-frame tokens `ids` matched to current-frame tokens `matches`."""
+    g = cfg.grid
+    ids, matches = np.asarray(ids, np.int64), np.asarray(matches, np.int64)
+    p1 = torch.from_numpy(np.stack([ids // g, ids % g], 1))
+    p2 = torch.from_numpy(np.stack([matches // g, matches % g], 1))
+    s_star, s_ = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), rows,
+                                 params.u_max, params.v_max, cfg.img_size)
+    return sr.velocity(s_star, s_, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
+
+
+def _first_mutual_in_order(order, nn1, nn2, k):
+    t = len(nn1)
+    mutual = np.asarray(nn2)[np.asarray(nn1)] == np.arange(t)
+    return np.array([x for x in order if mutual[x]][:k], dtype=np.int64)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -381,43 +410,47 @@ def test_16bit_modes_over_8_accepted_pairs(precision):
     depth = synth.depth_pattern()
     g, t, k = cfg.grid, cfg.tokens, params.num_pairs
     bars = MODE_BARS[precision]
-    agree1, agree2, same_sel, checked = [], [], 0, 0
+    agree1, agree2, same_fixture, same_draw = [], [], 0, 0
     for i, seed in enumerate(int(x) for x in blob["frame_seeds"]):
         case = golden_case(blob, f"pair{i}")
         des, cur = synth.frame_pair(cfg.img_size, seed)
-        # (1) given the reference's selection: v_c matches whenever nn_1 agrees at the selected tokens
+        toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+        S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
+        n1r, n2r = case["nn_1"].astype(np.int64), case["nn_2"].astype(np.int64)
+        # (1) the reference's own draw (fixture), EXPLICIT selection
         sel = _ids(case["points1"], g)
         v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
         det = eng.last_details(1)
-        assert int(st[0]) == 0 and np.all(np.isfinite(v.cpu().numpy()))
-        agree1.append(float((det["nn_1"][0] == case["nn_1"]).mean()))
-        agree2.append(float((det["nn_2"][0] == case["nn_2"]).mean()))
+        assert int(st[0]) == 0
+        a1 = _tie_tolerant_agreement(det["nn_1"][0], case["nn_1"], S, bars["tie"])
+        a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, bars["tie"])
+        agree1.append(a1)
+        agree2.append(a2)
+        assert a1 >= bars["agree1"] and a2 >= bars["agree2"], (i, a1, a2)
         np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=bars["sim_atol"])
-        if np.array_equal(det["nn_1"][0][sel], case["nn_1"][sel]):
-            checked += 1
-            assert _rel_l2(v.cpu().numpy()[0], case["v_c"]) <= 1e-9 <= VC_TOL
-        # (2) given the same visiting order: the device picks the same tokens iff its mutual-NN set agrees on the
-        # visited prefix; then v_c equals the oracle law on those tokens
+        dev_matches = det["nn_1"][0].astype(np.int64)[sel]
+        if np.array_equal(dev_matches, n1r[sel]):
+            same_fixture += 1
+            want = case["v_c"]
+        else:
+            want = _law_on(cfg, params, sel, dev_matches, depth, k)["v_c"]
+        assert _rel_l2(v.cpu().numpy()[0], want) <= 1e-9 <= VC_TOL, (i, "explicit")
+        # (2) a visiting order: the draw is exact given the device's own tables; v_c is the oracle's law on that draw
         order = np.random.default_rng(1000 + i).permutation(t).astype(np.int32)
-        n1r, n2r = case["nn_1"].astype(np.int64), case["nn_2"].astype(np.int64)
-        mutual = set(np.nonzero(n2r[n1r] == np.arange(t))[0].tolist())
-        want_sel = np.array([x for x in order if x in mutual][:k], dtype=np.int64)
         v2, st2 = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order[None])
         det2 = eng.last_details(1)
+        d1, d2 = det2["nn_1"][0].astype(np.int64), det2["nn_2"][0].astype(np.int64)
+        assert np.array_equal(d1, det["nn_1"][0]) and np.array_equal(d2, det["nn_2"][0])     # same frames, same tables
+        want_sel = _first_mutual_in_order(order, d1, d2, k)
         got_sel = det2["selected"][0, :k].astype(np.int64)
-        if np.array_equal(got_sel, want_sel) and np.array_equal(det2["nn_1"][0][want_sel], n1r[want_sel]):
-            same_sel += 1
-            p1 = torch.from_numpy(np.stack([want_sel // g, want_sel % g], 1))
-            p2 = torch.from_numpy(np.stack([n1r[want_sel] // g, n1r[want_sel] % g], 1))
-            s_star, s_ = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), k,
-                                         params.u_max, params.v_max, cfg.img_size)
-            ref = sr.velocity(s_star, s_, depth, params.f_x, params.f_y, params.c_x, params.c_y, params.lambda_)
-            assert _rel_l2(v2.cpu().numpy()[0], ref["v_c"]) <= 1e-9 <= VC_TOL
-    print(f"{precision}: argmax agreement with the fp32 oracle over 8 pairs: nn_1 mean {np.mean(agree1):.4f} min {min(agree1):.4f}, "
-          f"nn_2 mean {np.mean(agree2):.4f} min {min(agree2):.4f}; v_c checked (<= 1e-9) on {checked}/8 pairs given the "
-          f"reference selection, on {same_sel}/8 given the same visiting order (the rest drew different, valid features)")
-    assert np.mean(agree1) >= bars["agree"] and np.mean(agree2) >= bars["agree"]
-    assert checked >= 1
+        assert int(st2[0]) == 0 and len(want_sel) == k and np.array_equal(got_sel, want_sel), (i, "order draw")
+        assert _rel_l2(v2.cpu().numpy()[0], _law_on(cfg, params, want_sel, d1[want_sel], depth, k)["v_c"]) <= 1e-9 <= VC_TOL
+        ref_sel = _first_mutual_in_order(order, n1r, n2r, k)
+        same_draw += int(np.array_equal(ref_sel, want_sel) and np.array_equal(d1[want_sel], n1r[ref_sel]))
+    print(f"{precision}: arg-max agreement with the fp32 oracle over 8 pairs: nn_1 mean {np.mean(agree1):.4f} min {min(agree1):.4f}, "
+          f"nn_2 mean {np.mean(agree2):.4f} min {min(agree2):.4f}; v_c <= 1e-9 on 8/8 pairs in both selections; the fixture's "
+          f"matches at the fixture's draw on {same_fixture}/8, the oracle tables' ORDER draw on {same_draw}/8")
+    assert same_fixture >= bars["same_fixture"] and same_draw >= bars["same_draw"]
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -464,7 +497,111 @@ def test_forward_tokens_fp16_large_config(key):
     ref = _oracle_tokens(cfg, sd, frame)
     rel = float((got - ref).abs().max() / ref.abs().max())
     print(f"{key} fp16 tokens: max abs err / max abs = {rel:.3e}")
-    assert torch.isfinite(got).all() and rel <= 1e-2
+    assert torch.isfinite(got).all() and rel <= 5e-4        # fp16 tokens to 5e-4
+
+
+def test_forward_tokens_strided_full_size():
+    """SURVEY §8(f)3 at full size: dino_vits8 with stride 4 at 224² -> 55 x 55 = 3025 overlapping patches (the long-sequence
+    case the stride hack exists for, dinov2_extractor.py:122-144), pos_embed resampled 28 -> 55 (:94-118); fp32 tokens
+    against the oracle, all 12 blocks, both frames of a pair."""
+    cfg = config.vit_config("dino_vits8", 224, stride=4)
+    assert cfg.grid == 55 and cfg.tokens == 3025
+    sd = weights.synthetic_state_dict(cfg, 2)
+    frames = np.stack(synth.frame_pair(224, 20250901))
+    eng = _engine(cfg, config.ServoParams(dino_input_size=224, use_feature_binning=False), precision="fp32",
+                  max_pairs=1).load_state_dict(sd)
+    got = eng.forward_tokens(frames).cpu()
+    ref = _oracle_tokens(cfg, sd, frames)
+    assert got.shape == (2, 3026, 384)
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print(f"dino_vits8 stride 4, 3025 tokens, fp32: max abs err / max abs = {rel:.3e}")
+    assert rel <= 2e-5
+
+
+STRESS_BARS = {"fp32": 1e-4, "fp16": 5e-3, "bf16": 4e-2}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+def test_forward_tokens_with_trained_like_statistics(precision):
+    """Every other end-to-end fixture uses trunc-normal(0.02) weights: attention logits near 0, near-uniform softmax, no
+    outlier channels.  This one (weights.trained_like_state_dict) has peaky softmax rows (entropy 0.9 - 2.5 nats, checked
+    below on the oracle) and four residual channels 40-60 x above the median; tokens against the oracle PER CHANNEL, so that
+    the large channels cannot hide an error in the ordinary ones."""
+    import torch.nn.functional as F
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.trained_like_state_dict(cfg, 3)
+    frames = np.stack(synth.frame_pair(cfg.img_size, 77))
+    stages = vit_ref.block_tokens(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
+                                  mean=cfg.mean, std=cfg.std, return_all=True)
+    ref = stages[-1]
+    ents = []
+    for i in (0, 5, 11):                                             # the fixture is what it claims to be
+        y = F.layer_norm(stages[i], (cfg.dim,), sd[f"blocks.{i}.norm1.weight"], sd[f"blocks.{i}.norm1.bias"], cfg.ln_eps)
+        qkv = F.linear(y, sd[f"blocks.{i}.attn.qkv.weight"], sd[f"blocks.{i}.attn.qkv.bias"]).reshape(2, cfg.seq, 3, cfg.heads, 64)
+        q, k, _ = qkv.unbind(2)
+        a = ((q.transpose(1, 2) @ k.transpose(1, 2).transpose(-2, -1)) * 0.125).softmax(-1)
+        ents.append(float(-(a * a.clamp_min(1e-30).log()).sum(-1).mean()))
+    chan = ref.abs().amax(dim=(0, 1))
+    assert all(0.5 <= e <= 3.0 for e in ents), ents
+    assert float(chan.topk(4).values.min() / chan.median()) >= 30.0
+    eng = _engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision=precision,
+                  max_pairs=1).load_state_dict(sd)
+    got = eng.forward_tokens(frames).cpu()
+    per_chan = (got - ref).abs().amax(dim=(0, 1)) / chan
+    print(f"trained-like statistics, {precision}: softmax entropy {[round(e, 2) for e in ents]} nats, outlier / median channel "
+          f"{float(chan.max() / chan.median()):.0f}x, worst per-channel error {float(per_chan.max()):.3e} "
+          f"(median {float(per_chan.median()):.3e})")
+    assert torch.isfinite(got).all() and float(per_chan.max()) <= STRESS_BARS[precision]
+
+
+# BASELINE.json configs[4] (fp16 DINOv2 ViT-L/14 518², 1369 tokens) and configs[2] in the throughput dtype (bf16 DINO ViT-B/8
+# 448², 3136 tokens), END TO END in their own dtype: these are the sizes where the 16-bit modes take the Gram on the f16
+# matrix cores from a hi / lo split of the descriptors (correspond.hip), the 256-row GEMM tiles and the key-split attention.
+FULL16 = {("vitl14_518", "fp16"): dict(tie=3e-3, agree=0.90), ("vitb8_448", "bf16"): dict(tie=2e-2, agree=0.50)}
+
+
+@pytest.mark.parametrize("key,precision", list(FULL16))
+def test_compute_velocity_16bit_many_tokens_full_size(key, precision):
+    """(a) the device's arg-max tables are maxima of an fp64 Gram of the device's OWN descriptors up to 1e-6 ties (the f16
+    split Gram loses nothing that matters); (b) against the fp32 oracle every disagreement is a near-tie of the oracle's
+    similarity matrix at the mode's similarity error (top-1 / top-2 margins at thousands of tokens are ~1e-6, so the tables
+    are compared through S, not index by index); (c) the ORDER draw is exact given the device's tables and v_c equals the
+    oracle's law on that draw to 1e-9 (bar 1e-4)."""
+    bars = FULL16[(key, precision)]
+    blob = load_golden(f"e2e_{key}.npz")
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    depth = synth.depth_pattern()
+    t, k = cfg.tokens, params.num_pairs
+    order = np.random.default_rng(31).permutation(t).astype(np.int32)
+    v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order[None])
+    det = eng.last_details(1)
+    v = v.cpu().numpy()[0].copy()
+    d1, d2 = det["nn_1"][0].astype(np.int64), det["nn_2"][0].astype(np.int64)
+    assert int(st[0]) == 0 and int(det["info"][0, 2]) == 0
+    # (a) the device's own descriptors, exact Gram
+    d = eng.extract_descriptors(np.stack([des, cur])).double().cpu()[:, 0]
+    dn = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    S_dev = (dn[0] @ dn[1].T).numpy()
+    for got, M in ((d1, S_dev), (d2, S_dev.T)):
+        assert float((M.max(1) - M[np.arange(t), got]).max()) <= 1e-6, "an arg-max of the device Gram is not a maximum of the exact Gram"
+    np.testing.assert_allclose(det["sim_1"][0], S_dev.max(1), rtol=0, atol=2e-6)
+    # (b) the fp32 oracle
+    toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+    S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
+    a1 = _tie_tolerant_agreement(d1, S.argmax(1), S, bars["tie"])
+    a2 = _tie_tolerant_agreement(d2, S.argmax(0), S.T, bars["tie"])
+    desc_err = float(np.abs(S_dev - S).max())
+    print(f"{key} {precision}: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f} (every disagreement a tie "
+          f"<= {bars['tie']}); max |S_device - S_oracle| = {desc_err:.3e}")
+    assert a1 >= bars["agree"] and a2 >= bars["agree"] and desc_err <= bars["tie"]
+    # (c) the draw and the law
+    want_sel = _first_mutual_in_order(order, d1, d2, k)
+    assert len(want_sel) == k and np.array_equal(det["selected"][0, :k].astype(np.int64), want_sel)
+    assert _rel_l2(v, _law_on(cfg, params, want_sel, d1[want_sel], depth, k)["v_c"]) <= 1e-9 <= VC_TOL
 
 
 def test_batched_pairs_and_shared_goal():
@@ -622,6 +759,53 @@ def test_graph_replay_matches_eager(monkeypatch, many_tokens):
     for a, b in zip(results["0"], results["1"]):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
     assert not np.array_equal(results["1"][0][0], results["1"][1][0])     # different orders do give different draws
+
+
+def test_graph_mode_keeps_the_goal_cache_contract(monkeypatch):
+    """VITVS_GRAPH=1 and vitvs_set_goal together: a replayed graph runs none of the host code of the captured body, so the
+    goal-cache state is kept outside it.  A cached-goal graph must not be replayed once the goal rows were overwritten —
+    by a velocity call WITH I_des (replayed or captured) or by any other call that forwards frames — : include/vitvs.h
+    promises error -5 (VitvsError here), and after set_goal again the cached call equals the eager engine's bit for bit."""
+    from vitvs_amd.engine import VitvsError
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vits16_224"])
+    des2, _ = synth.frame_pair(cfg.img_size, 4711)
+    dev = torch.device("cuda")
+    I_cur, I_des, I_des2 = (torch.from_numpy(x[None]).to(dev) for x in (cur, des, des2))
+    Z = torch.from_numpy(synth.depth_pattern()[None]).to(dev)
+    K = torch.tensor([params.intrinsics()], dtype=torch.float64, device=dev)
+    order = torch.randperm(cfg.tokens, generator=torch.Generator().manual_seed(2)).to(torch.int32)[None].to(dev)
+    monkeypatch.setenv("VITVS_GRAPH", "0")
+    eager = _engine(cfg, params, precision="bf16", max_pairs=1).load_state_dict(sd)
+    eager.set_goal(I_des)
+    want = eager.compute_velocity_dev(I_cur, None, Z, K, _lib.SELECT_ORDER, order)[0].cpu().numpy().copy()
+    monkeypatch.setenv("VITVS_GRAPH", "1")
+    eng = _engine(cfg, params, precision="bf16", max_pairs=1).load_state_dict(sd)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        def call(goal):
+            v, _ = eng.compute_velocity_dev(I_cur, goal, Z, K, _lib.SELECT_ORDER, order)
+            torch.cuda.synchronize()
+            return v.cpu().numpy().copy()
+        eng.set_goal(I_des)
+        torch.cuda.synchronize()
+        assert np.array_equal(call(None), want)              # captures the cached-goal graph
+        assert np.array_equal(call(None), want)              # replays it
+        other = call(I_des2)                                 # captures a graph WITH I_des: the goal rows now hold des2
+        assert not np.array_equal(other, want)
+        with pytest.raises(VitvsError):
+            call(None)                                       # the cached-goal graph exists, but the cache is gone
+        eng.set_goal(I_des)
+        torch.cuda.synchronize()
+        assert np.array_equal(call(None), want)              # re-armed: the replay reads the fresh goal rows
+        assert np.array_equal(call(I_des2), other)           # REPLAY of the I_des graph overwrites them again ...
+        with pytest.raises(VitvsError):
+            call(None)                                       # ... and that is known without running the body's host code
+        eng.set_goal(I_des)
+        eng.forward_tokens(cur[None])                        # another entry point forwards frames of its own
+        with pytest.raises(VitvsError):
+            call(None)
 
 
 def test_two_handles_interleaved():
@@ -833,8 +1017,18 @@ def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
                                  selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
     det = eng.last_details(1)
     assert int(st[0]) == 0 and int(det["info"][0, 2]) == 1          # same_image flag
-    k = params.num_pairs                                             # rows beyond num_pairs belong to larger calls (max_rows = 48)
-    assert np.array_equal(det["s_uv"][0, :k, :2], det["s_uv"][0, :k, 2:])
+    k = params.num_pairs
+    assert np.array_equal(det["s_uv"][0, :, :2], det["s_uv"][0, :, 2:]) and np.any(det["s_uv"][0, :k] != 0)
+    # rows from n_feature_rows on are DEFINED (include/vitvs.h): -1 / 0, whatever an earlier 48-pair call left behind
+    eng.compute_velocity(des, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER, num_pairs=48,
+                         selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
+    assert np.all(eng.last_details(1)["selected"][0] >= 0)
+    eng.compute_velocity(des, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER,
+                         selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
+    det = eng.last_details(1)
+    assert eng.max_rows == 48 and int(det["info"][0, 1]) == k
+    assert np.all(det["selected"][0, k:] == -1) and np.all(det["s_uv"][0, k:] == 0) and np.all(det["feat"][0, k:] == 0)
+    assert np.all(det["L"][0, :, 2 * k:] == 0) and np.any(det["L"][0, :6, :2 * k] != 0)
     assert np.all(v.cpu().numpy() == 0.0)
 
 

@@ -693,8 +693,6 @@ struct UpdateArgs {
 
 static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
-    if (!u.I_des && h->goal_frames != n_des)
-        return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
     h->desc_keys = u.n_pairs * h->T;
     // cached goal: only the current frames (images n_des .. n_img - 1 of the call's list) go through the network
     int rc = u.I_des ? forward_chain(h, 0, n_img, n_des, u.I_des, u.I_cur, h->part, st)
@@ -811,6 +809,11 @@ int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* 
     if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
     hipStream_t st = as_stream(stream);
     const UpdateArgs u{n_pairs, des_shared, select_mode, np, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
+    // The goal cache is host-side state of the handle: it is checked and invalidated here, on every call, and never
+    // inside the body that a hipGraph captures (a replay runs none of the body's host code).
+    if (!I_des && h->goal_frames != (des_shared ? 1 : n_pairs))
+        return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
+    if (I_des) h->goal_frames = 0;              // the call forwards goal frames of its own over the cached rows
     if (h->use_graphs && !h->timing && st != nullptr) return replay_update(h, u, st);
     return enqueue_update(h, u, st);
 }
@@ -859,11 +862,25 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
     if (nn_1) VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
     if (nn_2) VITVS_HIP_CHECK(hipMemcpy(nn_2, h->nn2, P * T * 4, hipMemcpyDeviceToHost));
     if (sim_1) VITVS_HIP_CHECK(hipMemcpy(sim_1, h->sim1, P * T * 4, hipMemcpyDeviceToHost));
-    if (info) VITVS_HIP_CHECK(hipMemcpy(info, h->info, P * 8 * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> inf(P * 8);
+    VITVS_HIP_CHECK(hipMemcpy(inf.data(), h->info, P * 8 * 4, hipMemcpyDeviceToHost));
+    if (info) memcpy(info, inf.data(), P * 8 * 4);
     if (selected) VITVS_HIP_CHECK(hipMemcpy(selected, h->sel_out, P * R * 4, hipMemcpyDeviceToHost));
     if (s_uv) VITVS_HIP_CHECK(hipMemcpy(s_uv, h->s_uv, P * R * 4 * 4, hipMemcpyDeviceToHost));
     if (feat) VITVS_HIP_CHECK(hipMemcpy(feat, h->feat, P * R * 4 * 8, hipMemcpyDeviceToHost));
     if (L) VITVS_HIP_CHECK(hipMemcpy(L, h->Lws, P * 7 * 2 * R * 8, hipMemcpyDeviceToHost));
+    // The kernel writes the first n_feature_rows (info[1]) rows of a pair; the workspace rows behind them may still hold
+    // an earlier, larger call's values.  The copies handed out are defined everywhere: selected = -1, everything else 0.
+    for (size_t b = 0; b < P; ++b) {
+        const size_t n = std::min<size_t>(R, (size_t)std::max(inf[b * 8 + 1], 0));
+        for (size_t k = n; k < R; ++k) {
+            if (selected) selected[b * R + k] = -1;
+            if (s_uv) memset(s_uv + (b * R + k) * 4, 0, 16);
+            if (feat) memset(feat + (b * R + k) * 4, 0, 32);
+        }
+        if (L)
+            for (size_t c = 0; c < 7; ++c) memset(L + (b * 7 + c) * 2 * R + 2 * n, 0, (2 * R - 2 * n) * 8);
+    }
     return 0;
 }
 

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -508,6 +509,11 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         }
         __syncthreads();
         if (*flag != splits - 1) return;                       // not the last arriver of this query block
+        // EVERY wave of the merging workgroup takes the agent-scope acquire (one buffer_inv sc1 per wave) before its plain
+        // loads of the other ranges' states: lane 0's fence above orders only its own wave in the HIP memory model, and
+        // the states may sit in this CU's L1 from an earlier launch.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // merge the ranges' states in range order; this workgroup's own state comes from its registers
         const float* st0 = ws + ((size_t)(item * splits) * 4 + wave) * kAttnStateFloats + 4 * lane;
         float m_tot = -INFINITY;
@@ -867,32 +873,40 @@ size_t attention_ticket_count(int n_img, int N, int H) {
     return attention_splits(n_img, N, H) > 1 ? (size_t)((N + 127) / 128) * H * n_img : 0;
 }
 
-// The pointer-only operator hook (vitvs_op_attention) has no handle to own the key-split workspace: one per device, grown on
-// demand (synchronising; handles pre-size their own at creation so that nothing is allocated on the call path).
-static AttnWorkspace* shared_attention_workspace(size_t floats, size_t tickets) {
+// The pointer-only operator hook (vitvs_op_attention) has no handle to own the key-split workspace: one per (device, stream),
+// grown on demand.  A launch's states and tickets are private to its stream's workspace, so two streams (or threads) running
+// split attention at the same time never share a slot; launches on ONE stream are ordered by the stream.  Growth allocates a
+// new block and keeps the old one alive (a launch in flight, or a captured graph, may still hold its address) and is refused
+// while the stream is capturing (an allocation + memset cannot be recorded).  Handles pre-size their own workspace at creation,
+// so the product path never comes here.
+static const AttnWorkspace* shared_attention_workspace(hipStream_t stream, size_t floats, size_t tickets) {
+    struct Slot { int dev; hipStream_t stream; AttnWorkspace ws; size_t cap_f, cap_t; };
     static std::mutex mu;
-    static AttnWorkspace per_device[64];
-    static size_t cap_f[64], cap_t[64];
+    static std::vector<Slot*> slots;            // never freed: the hook is a test / tool entry point, the set of streams is small
     std::lock_guard<std::mutex> lock(mu);
     const int dev = current_device();
-    if (dev < 0 || dev >= 64) return nullptr;
-    AttnWorkspace& w = per_device[dev];
-    if (floats > cap_f[dev]) {
-        (void)hipDeviceSynchronize();
-        if (w.state) (void)hipFree(w.state);
-        if (hipMalloc((void**)&w.state, floats * sizeof(float)) != hipSuccess) { w.state = nullptr; cap_f[dev] = 0; return nullptr; }
-        cap_f[dev] = floats;
+    if (dev < 0) return nullptr;
+    Slot* sl = nullptr;
+    for (Slot* c : slots)
+        if (c->dev == dev && c->stream == stream) sl = c;
+    if (!sl) { sl = new Slot{dev, stream, AttnWorkspace{}, 0, 0}; slots.push_back(sl); }
+    if (floats <= sl->cap_f && tickets <= sl->cap_t) return &sl->ws;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    if (floats > sl->cap_f) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, floats * sizeof(float)) != hipSuccess) return nullptr;
+        sl->ws.state = p;                       // the previous block stays allocated
+        sl->cap_f = floats;
     }
-    if (tickets > cap_t[dev]) {
-        (void)hipDeviceSynchronize();
-        if (w.tickets) (void)hipFree(w.tickets);
-        if (hipMalloc((void**)&w.tickets, tickets * sizeof(int)) != hipSuccess || hipMemset(w.tickets, 0, tickets * sizeof(int)) != hipSuccess) {
-            w.tickets = nullptr; cap_t[dev] = 0; return nullptr;
-        }
-        (void)hipDeviceSynchronize();          // the zeros are in place before any stream's launch draws a ticket
-        cap_t[dev] = tickets;
+    if (tickets > sl->cap_t) {
+        int* p = nullptr;
+        if (hipMalloc((void**)&p, tickets * sizeof(int)) != hipSuccess || hipMemset(p, 0, tickets * sizeof(int)) != hipSuccess) return nullptr;
+        (void)hipDeviceSynchronize();           // the zeros are in place before this stream's next launch draws a ticket
+        sl->ws.tickets = p;
+        sl->cap_t = tickets;
     }
-    return &w;
+    return &sl->ws;
 }
 
 template <typename HT>
@@ -913,7 +927,7 @@ static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, 
         const int sp = attention_splits(n_img, N, H);
         const int units = ((N + 127) / 128) * H * n_img * sp;
         if (sp > 1) {
-            if (!ws) ws = shared_attention_workspace(attention_workspace_floats(n_img, N, H), attention_ticket_count(n_img, N, H));
+            if (!ws) ws = shared_attention_workspace(stream, attention_workspace_floats(n_img, N, H), attention_ticket_count(n_img, N, H));
             if (!ws || !ws->state || !ws->tickets) return -3;
         }
         int lds = 3 * 2 * 64 * 128;

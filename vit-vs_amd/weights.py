@@ -69,6 +69,30 @@ def synthetic_state_dict(cfg: ViTConfig, seed: int = 0, affine_jitter: bool = Tr
     return sd
 
 
+def trained_like_state_dict(cfg: ViTConfig, seed: int = 0, qk_gain: float = 9.0, outlier_channels: int = 4,
+                            outlier_gain: float = 150.0) -> Dict[str, torch.Tensor]:
+    """A synthetic checkpoint with the statistics a TRAINED ViT shows and trunc-normal(0.02) initialisation does not
+    (no checkpoints offline): the query / key rows of every ``attn.qkv.weight`` are scaled by ``qk_gain`` so that the
+    attention logits spread over several units (peaky softmax rows, entropy of 1-2.5 nats at 197 tokens instead of the
+    near-uniform ln 197 = 5.3), and ``outlier_channels`` residual channels end up 40-60 x larger than the median channel
+    (the "massive activation" channels of trained ViTs: the rows of the first two blocks' ``mlp.fc2.weight`` / bias that
+    write those channels are scaled), which dominate every LayerNorm's statistics from block 1 on and stress the 16-bit
+    GEMMs' dynamic range.  Deterministic for a seed; used by the stress parity tests only."""
+    sd = synthetic_state_dict(cfg, seed)
+    d = cfg.dim
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed + 977)
+    chans = torch.randperm(d, generator=gen)[:outlier_channels]
+    for i in range(cfg.blocks_run):
+        w = sd[f"blocks.{i}.attn.qkv.weight"]
+        w[: 2 * d] *= qk_gain                                  # q and k rows (the bias is scaled with them)
+        sd[f"blocks.{i}.attn.qkv.bias"][: 2 * d] *= qk_gain
+        if i < 2:
+            sd[f"blocks.{i}.mlp.fc2.weight"][chans] *= outlier_gain
+            sd[f"blocks.{i}.mlp.fc2.bias"][chans] = outlier_gain * 0.02 * torch.sign(sd[f"blocks.{i}.mlp.fc2.bias"][chans] + 1e-12)
+    return sd
+
+
 def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
     """Positional encoding for a ``grid x grid`` token grid, shape (1 + grid², D), fp32.
 
