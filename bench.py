@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
+STATS_PROFILE = os.path.join("profiles", "r03_kernel_stats_bf16.csv")   # rocprofv3 --kernel-trace --stats of the same command
 
 
 # ----------------------------------------------------------------------------------------------- launcher
@@ -55,10 +56,45 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def visible_devices() -> int:
-    """Devices this process could use, WITHOUT initialising HIP (torch.cuda.device_count() does not, on this image)."""
-    import torch
-    return int(torch.cuda.device_count())
+def _listed(var):
+    """Entries of a *_VISIBLE_DEVICES variable (None when unset; an empty string hides every device)."""
+    val = os.environ.get(var)
+    if val is None:
+        return None
+    return [x for x in val.split(",") if x.strip() != ""]
+
+
+def visible_devices(sysfs="/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process's children could use, counted WITHOUT loading torch or HIP in this process (a parent that has
+    initialised the GPU must not start the ranks: the pool forbids exec from such a process).  KFD topology nodes with
+    SIMDs are GPUs (CPU nodes have simd_count 0); ROCR_/HIP_/CUDA_VISIBLE_DEVICES narrow the count the way the runtime
+    applies them.  If the topology is not readable, ask a throwaway child (started before anything else, it exits before
+    any rank starts)."""
+    n = None
+    try:
+        n = 0
+        for node in sorted(os.listdir(sysfs)):
+            try:
+                with open(os.path.join(sysfs, node, "properties")) as fh:
+                    props = dict(ln.split(None, 1) for ln in fh if " " in ln)
+            except OSError:
+                continue      # a node of another container's cgroup: not ours
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        n = None
+    if n is None:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=300)
+        try:
+            n = int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            n = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = _listed(var)
+        if lst is not None:
+            n = min(n, len(lst))
+    return n
 
 
 def rank_environments(n_ranks: int, port: int, base_env=None):
@@ -79,9 +115,15 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(args, argv, script=None) -> int:
-    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU), wait, relay rank 0's JSON line.
-    This process never touches a GPU (no exec after GPU initialisation, no fork of a GPU-initialised process)."""
+def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU), watch ALL of them, relay rank 0's JSON
+    line.  This process never touches a GPU (no torch import, no HIP call: `visible_devices`), so starting children from it
+    is neither an exec after GPU initialisation nor a fork of a GPU-initialised process.  The first rank that exits
+    non-zero ends the run within seconds: the others are terminated (then killed), its rank and the tail of its stderr
+    are printed, and the exit code is 1 — a dead rank never leaves the others waiting in a collective until a time limit
+    kills the whole job without a cause on record.  An overall deadline (VITVS_BENCH_DEADLINE_S, default 900 s) bounds
+    the run the same way."""
+    import tempfile
     n = args.gpus
     share = os.environ.get("VITVS_BENCH_SHARE_GPU") == "1"     # rehearsal: N ranks on fewer GPUs (gloo)
     have = visible_devices()
@@ -93,18 +135,62 @@ def launch_ranks(args, argv, script=None) -> int:
     if have < 1:
         print("bench.py: no HIP device visible", file=sys.stderr)
         return 2
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("VITVS_BENCH_DEADLINE_S", "900"))
     envs = rank_environments(n, free_port())
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="vitvs_bench_")
+    procs, outs, errs = [], [], []
     for r, env in enumerate(envs):
+        outs.append(open(os.path.join(logdir, f"rank{r}.out"), "w+"))
+        errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    if any(codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        sys.stdout.write(out0 or "")
+                                      stdout=outs[r], stderr=errs[r], text=True, start_new_session=True))
+
+    def tail(fh, lines=15):
+        fh.flush()
+        fh.seek(0)
+        return "".join(fh.readlines()[-lines:])
+
+    def stop_all():
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+        t_end = time.monotonic() + 5.0
+        for p_ in procs:
+            try:
+                p_.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+                p_.wait()
+
+    t_stop = time.monotonic() + deadline_s
+    failed = None
+    while True:
+        codes = [p_.poll() for p_ in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_stop:
+            failed = -1
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        stop_all()
+        if failed < 0:
+            print(f"bench.py: no result after {deadline_s:.0f} s; ranks terminated. rank 0 stderr tail:\n{tail(errs[0])}", file=sys.stderr)
+        else:
+            print(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; the other ranks were terminated. "
+                  f"Its stderr tail:\n{tail(errs[failed])}", file=sys.stderr)
         return 1
-    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    out0 = tail(outs[0], lines=50)
+    for r in range(n):
+        t_ = tail(errs[r], lines=5)
+        if t_.strip() and os.environ.get("VITVS_BENCH_VERBOSE") == "1":
+            print(f"[rank {r} stderr] {t_}", file=sys.stderr)
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if not line:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         return 1
@@ -208,16 +294,17 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def oracle_update(cfg, sd, des, cur, depth, params, order):
+def oracle_update(cfg, sd, des, cur, depth, params, order, exact_order=False):
     """One update by the CPU oracle under a given visiting order: tokens -> tables -> the first num_pairs mutual NNs
-    met in `order` -> the reference's law.  Returns dict(nn_1, nn_2, selected, v_c, status)."""
+    met in `order` -> the reference's law.  Returns dict(nn_1, nn_2, selected, v_c, status).  `exact_order` evaluates the
+    similarity matrix the way the reference does (a Python loop over the T tokens, vitvs_v2.py:49-56) instead of one matmul."""
     import numpy as np
     import torch
     from oracle import servo_ref as sr
     from oracle import vit_ref
     toks = vit_ref.block_tokens(sd, np.stack([des, cur]), patch=cfg.patch, stride=cfg.stride, heads=cfg.heads,
                                 layer=cfg.layer, mean=cfg.mean, std=cfg.std)[:, 1:]
-    sim = sr.cosine_matrix(toks[0], toks[1], exact_order=False)
+    sim = sr.cosine_matrix(toks[0], toks[1], exact_order=exact_order)
     _, nn1, _, nn2 = sr.nearest_neighbours(sim)
     nn1, nn2 = nn1.numpy(), nn2.numpy()
     t, g, k = cfg.tokens, cfg.grid, params.num_pairs
@@ -245,32 +332,50 @@ def oracle_law(cfg, params, sel, matches, depth):
     return dict(v_c=res["v_c"], status=0 if (len(sel) >= 4 or len(sel) == params.num_pairs) else 2)
 
 
-def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=18.0):
-    """The CPU oracle timed on this host: all usable threads (median, p90) and one thread."""
+def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=12.0):
+    """The CPU oracle timed on this host: on the threads this process may use (its CPU affinity — a GPU
+    box gives one GPU's share of the host), on os.cpu_count() threads (every core of the node, as §8(d) words it;
+    oversubscribed when the affinity is narrower), on one thread, and in the reference's own shape — the similarity
+    matrix by a Python loop over the T tokens (vitvs_v2.py:49-56) instead of one matmul.  `value` is the best of the
+    multi-thread figures with the matmul form; every figure is in the object."""
     import numpy as np
     import torch
     order = np.arange(cfg.tokens)
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    usable = max(1, len(os.sched_getaffinity(0)))
+    host = os.cpu_count() or usable
 
-    def timed(n_threads, budget, at_most):
+    def timed(n_threads, budget, at_most, exact=False):
         torch.set_num_threads(n_threads)
-        oracle_update(cfg, sd, des, cur, depth, params, order)     # warm-up
+        oracle_update(cfg, sd, des, cur, depth, params, order, exact)     # warm-up
         times, t_end = [], time.perf_counter() + budget
         while len(times) < at_most and (time.perf_counter() < t_end or len(times) < 2):
             t0 = time.perf_counter()
-            oracle_update(cfg, sd, des, cur, depth, params, order)
+            oracle_update(cfg, sd, des, cur, depth, params, order, exact)
             times.append(time.perf_counter() - t0)
         return times
-    many = timed(threads, budget_s, 20)
-    one = timed(1, 6.0, 5)
-    torch.set_num_threads(threads)
+    legs = {}
+    for n_thr in sorted({min(16, usable), usable, host}):
+        legs[n_thr] = timed(n_thr, budget_s if n_thr == min(16, usable) else 4.0, 20)
+    best_thr = min(legs, key=lambda k_: float(np.median(legs[k_])))
+    many = legs[best_thr]
+    loop = timed(best_thr, 4.0, 10, exact=True)
+    one = timed(1, 4.0, 5)
+    torch.set_num_threads(min(16, usable))
     med, p90, med1 = float(np.median(many)), float(np.percentile(many, 90)), float(np.median(one))
-    return dict(value=round(1.0 / med, 3), unit="updates/s", cores=threads, kind="port",
+    medl = float(np.median(loop))
+    return dict(value=round(1.0 / med, 3), unit="updates/s", cores=best_thr, kind="port",
                 p90_ms=round(p90 * 1e3, 2), median_ms=round(med * 1e3, 2), threads_1_value=round(1.0 / med1, 3),
-                threads_1_median_ms=round(med1 * 1e3, 2), cpu_model=cpu_model(), host_cpus=os.cpu_count(),
-                sample=f"{len(many)} updates of the same {cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair on {threads} "
-                       f"threads (median {med * 1e3:.1f} ms, p90 {p90 * 1e3:.1f} ms) and {len(one)} on 1 thread (median "
-                       f"{med1 * 1e3:.1f} ms): PyTorch-CPU fp32 forward + reference correspondence and law (numpy pinv)")
+                threads_1_median_ms=round(med1 * 1e3, 2), cpu_model=cpu_model(), host_cpus=host, usable_cpus=usable,
+                by_threads={str(k_): dict(value=round(1.0 / float(np.median(v_)), 3), median_ms=round(float(np.median(v_)) * 1e3, 2),
+                                          updates=len(v_)) for k_, v_ in legs.items()},
+                reference_loop=dict(value=round(1.0 / medl, 3), median_ms=round(medl * 1e3, 2), threads=best_thr, updates=len(loop),
+                                    note="the reference's chunk_cosine_sim: a Python loop over the T tokens (vitvs_v2.py:49-56); "
+                                         "same forward and law"),
+                sample=f"{len(many)} updates of the same {cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair on {best_thr} "
+                       f"threads (median {med * 1e3:.1f} ms, p90 {p90 * 1e3:.1f} ms; tried {sorted(legs)} threads, {usable} usable "
+                       f"of {host} host CPUs), {len(loop)} with the reference's per-token similarity loop (median {medl * 1e3:.1f} "
+                       f"ms) and {len(one)} on 1 thread (median {med1 * 1e3:.1f} ms): PyTorch-CPU fp32 forward + reference "
+                       f"correspondence and law (numpy pinv)")
 
 
 def parity_block(eng, cfg, sd, params, des, cur, depth_np, I_cur, I_des, Z, K, order_row, _lib):
@@ -346,11 +451,14 @@ def run_rank(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
         backend = os.environ.get("VITVS_DIST_BACKEND", "nccl")
+        # a rank that never arrives fails the rendezvous (and every later collective) after 120 s, not after the default 10 min
+        tmo = datetime.timedelta(seconds=float(os.environ.get("VITVS_DIST_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     cfg = config.baseline_config(args.config)
     binned = False  # north_star path: token descriptors (binning is a tested option, not the headline)
@@ -424,9 +532,16 @@ def run_rank(args):
             elapsed = float(te.item())
         status_host = status.cpu().numpy().copy()
         v_host = v_slots[(args.warmup + args.steps - 1) & 1].cpu().numpy().copy() if async_gather else v.cpu().numpy().copy()
-        gathered_ok = None
+        gathered_ok, ranks_seen = None, None
         if multi and not async_gather:
-            gathered_ok = bool(torch.equal(v_all[rank * B:(rank + 1) * B], v))    # this rank's rows of the gathered table
+            ok = torch.tensor([int(torch.equal(v_all[rank * B:(rank + 1) * B], v))], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # EVERY rank finds its own rows in the gathered table
+            gathered_ok = bool(ok.item())
+        if multi:
+            # ranks the communicator really spans: every rank contributes a one, the sum must be the world size
+            seen = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+            ranks_seen = int(seen.item())
 
         # single-update latency with a host synchronisation per update (a control loop's view)
         lat = []
@@ -546,6 +661,22 @@ def run_rank(args):
                                   command=blob.get("command"), mfma_busy_cycles_per_launch=entry.get("mfma_busy_cycles_per_launch"),
                                   note="separate --pmc FETCH_SIZE / WRITE_SIZE (and SQ_VALU_MFMA_BUSY_CYCLES) passes; "
                                        "FETCH_SIZE doubled per the gfx950 correction")
+    # the committed rocprofv3 --stats summary of the same command: average duration of the same symbol, so that the line and
+    # profiles/ can be reconciled mechanically (it is a record of ANOTHER run, on another box of the pool: +-4 %)
+    from_profile = None
+    stats_path = os.path.join(ROOT, STATS_PROFILE)
+    if os.path.isfile(stats_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1 and symbol:
+        import csv
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from symbols import short as short_symbol          # rocprofv3's (mangled) kernel names -> the names used here
+        with open(stats_path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Name", "")
+                if short_symbol(name) == symbol:
+                    calls, avg_ns = int(row["Calls"]), float(row["AverageNs"])
+                    from_profile = dict(file=STATS_PROFILE, name=name[:120], calls=calls, avg_ns=round(avg_ns, 1),
+                                        total_ms=round(calls * avg_ns * 1e-6, 3))
+                    break
     mfma_bound = dom in ("qkv", "fc1", "attention", "patch_embed", "gram_argmax", "linear_partial(proj+fc2)")
     if mfma_bound:
         peak = PEAK_MFMA["fp32" if dom == "gram_argmax" else args.precision]
@@ -553,6 +684,10 @@ def run_rank(args):
                     unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
                     avg_launch_us=round(avg_s * 1e6, 3))
+        if from_profile:
+            from_profile["achieved"] = round(fl / (from_profile["avg_ns"] * 1e-9) / 1e12, 3)
+            from_profile["frac"] = round(fl / (from_profile["avg_ns"] * 1e-9) / peak, 5)
+            roof["recomputed_from_profile"] = from_profile
         if plain and dom == "linear_partial(proj+fc2)":
             # the same kernel in a chain of plain launches (what the un-instrumented step pays per launch)
             p_us = sum(plain[c] * kernels[c]["launches_per_step"] for c in members) / launches
@@ -562,6 +697,10 @@ def run_rank(args):
         roof = dict(kernel=symbol, classes=members, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9,
                     unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=by, avg_launch_us=round(avg_s * 1e6, 3))
+        if from_profile:
+            from_profile["achieved"] = round(by / (from_profile["avg_ns"] * 1e-9) / 1e9, 2)
+            from_profile["frac"] = round(by / (from_profile["avg_ns"] * 1e-9) / PEAK_HBM, 5)
+            roof["recomputed_from_profile"] = from_profile
 
     out = dict(
         metric="servo_updates_per_sec", value=round(value, 2), unit="updates/s", n_gpus=world, steps=args.steps,
@@ -591,6 +730,11 @@ def run_rank(args):
     )
     if gathered_ok is not None:
         out["gathered_rows_match_local"] = gathered_ok
+    if ranks_seen is not None:
+        out["rccl_ranks_seen"] = ranks_seen
+        out["dist_backend"] = os.environ.get("VITVS_DIST_BACKEND", "nccl")
+        if ranks_seen != world:
+            raise SystemExit(f"the communicator spans {ranks_seen} ranks, expected {world}")
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, des_np[0], cur_np[0], depth_np, params)
     if rank == 0:

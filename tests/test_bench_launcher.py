@@ -86,3 +86,75 @@ def test_launcher_reports_failing_rank_and_mislabelled_line(bench, monkeypatch, 
     """)
     assert bench.launch_ranks(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"], script=lying) == 1
     assert "n_gpus=1" in capsys.readouterr().err
+
+
+def test_crashing_rank_ends_the_run_in_seconds_and_names_itself(bench, monkeypatch, tmp_path, capsys):
+    """Rank 2 dies during start-up while the others would wait in a rendezvous for minutes: the launcher must end within
+    seconds, terminate the waiting ranks, and print the dead rank with the tail of ITS stderr (ranks > 0 used to have none)."""
+    import time
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "visible_devices", lambda: 4)
+    pids = tmp_path / "pids"
+    pids.mkdir()
+    script = _stub(tmp_path, f"""
+        import os, sys, time
+        open(os.path.join({str(pids)!r}, os.environ["RANK"]), "w").write(str(os.getpid()))
+        if os.environ["RANK"] == "2":
+            time.sleep(0.5)
+            print("hipErrorNoDevice: rank 2 found no GPU", file=sys.stderr)
+            sys.exit(7)
+        time.sleep(600)          # the others: stuck in init_process_group
+    """)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(bench.parse_args(["--gpus", "4"]), ["--gpus", "4"], script=script)
+    took = time.monotonic() - t0
+    err = capsys.readouterr().err
+    assert rc == 1 and took < 20.0
+    assert "rank 2 exited with code 7" in err and "rank 2 found no GPU" in err
+    for r in ("0", "1", "3"):                                   # nobody is left behind holding a GPU
+        pid = int((pids / r).read_text())
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+
+
+def test_overall_deadline_terminates_hung_ranks(bench, monkeypatch, tmp_path, capsys):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "visible_devices", lambda: 2)
+    script = _stub(tmp_path, """
+        import time
+        time.sleep(600)
+    """)
+    rc = bench.launch_ranks(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"], script=script, deadline_s=1.0)
+    assert rc == 1 and "no result after 1 s" in capsys.readouterr().err
+
+
+def test_device_count_reads_the_kfd_topology_without_torch(bench, monkeypatch, tmp_path):
+    """The launcher counts GPUs from /sys/class/kfd (nodes with SIMDs), narrowed by *_VISIBLE_DEVICES, and never imports
+    torch or opens HIP for it."""
+    topo = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU nodes, three GPUs
+        d = topo / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    had_torch = "torch" in sys.modules
+    assert bench.visible_devices(str(topo)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_devices(str(topo)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_devices(str(topo)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_devices(str(topo)) == 0
+    assert ("torch" in sys.modules) == had_torch
+
+
+def test_launcher_parent_never_imports_torch():
+    """`python bench.py --gpus N` (no WORLD_SIZE) must reach its refusal without torch in the parent process."""
+    import subprocess
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '64']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    rc = e.code\n"
+            "print('torch' in sys.modules, rc)") % os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "VITVS_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.stdout.strip().splitlines()[-1] == "False 2", (r.stdout, r.stderr)

@@ -118,13 +118,17 @@ def test_closed_loop_converges_and_keeps_its_state(precision):
     sl = loop.ServoLoop(ctl, np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]), get_pose=sim.get_pose, apply_twist=sim.apply_twist,
                         sense=sim.sense, max_iterations=360, log=logs.append)
     res = sl.run()
-    # (ii) ended by the convergence monitor at the iteration cap, not by an abort or an exception
-    assert res is not None and res.iteration_count == 360 and "Maximum iterations reached" in logs
+    # (ii) ended by the convergence monitor — its velocity-window rule or the iteration cap, whichever comes first after
+    # the 300-iteration floor (vitvs_v2.py:345-421) — not by an abort or an exception
+    n = res.iteration_count if res is not None else 0
+    assert res is not None and 300 <= n <= 360
+    assert ("Maximum iterations reached" in logs) != ("Velocity trend indicates convergence - checking final error" in logs)
+    assert (n == 360) == ("Maximum iterations reached" in logs)
     assert not any("Aborting" in m or "Error" in m for m in logs)
     assert all(s in (0, 2) for s in status) and ctl.feature_failure_count == 0
     start, end = float(np.mean(feat_err[:5])), float(np.mean(feat_err[-60:]))
     p0, r0 = sl.initial_error_translation, sl.initial_error_rotation
-    print(f"closed loop {precision}: feature error {start:.4f} -> {end:.4f} ({100 * (1 - end / start):.1f} % down), pose error "
+    print(f"closed loop {precision}: {n} updates, ended by '{logs[-1]}'; feature error {start:.4f} -> {end:.4f} ({100 * (1 - end / start):.1f} % down), pose error "
           f"{p0:.2f} cm / {r0:.2f} deg -> {res.position_error:.2f} cm / {res.orientation_error:.2f} deg, "
           f"lowest {res.lowest_position_error:.2f} cm / {res.lowest_orientation_error:.2f} deg")
     assert abs(p0 - 5.0) < 1e-9 and abs(r0 - 5.0) < 1e-6
@@ -132,7 +136,7 @@ def test_closed_loop_converges_and_keeps_its_state(precision):
     assert res.position_error <= 0.8 * p0 and res.orientation_error <= 0.8 * r0
     assert res.position_error <= 2 * p0                                 # never near the divergence abort
     # (iii) >= 300 consecutive device updates: EMA state, history and the run's arrays against a host replay
-    assert len(raw) == 360 and sim.frames == 360
+    assert len(raw) == n and sim.frames == n
     ema = sr.Ema(params.ema_alpha)
     replay = [ema.update(v) for v in raw]
     assert np.array_equal(np.array(ctl.velocity_vector_history), np.array(replay[-200:]))   # capped at 200, config.yaml:37
@@ -140,4 +144,4 @@ def test_closed_loop_converges_and_keeps_its_state(precision):
     assert np.array_equal(res.average_velocities, np.array([np.mean(np.abs(v)) for v in replay]))
     lin = np.array([sr.twist_remap(v, params.max_velocity)[0] for v in replay])
     assert np.array_equal(np.stack([res.applied_velocity_x, res.applied_velocity_y, res.applied_velocity_z], 1), lin)
-    assert len(res.position_history) == 360
+    assert len(res.position_history) == n and len(res.velocity_mean_100) == n
