@@ -35,10 +35,17 @@ VITVS_API int vitvs_op_linear_residual(int32_t precision, const void* A, const v
 VITVS_API int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
                        int32_t D, float eps, void* stream);
 /* out[n_img*N][H*64] = softmax(q k^T / 8) v per (image, head); qkv [n_img*N][3*H*64].  From 512 tokens on the keys of a query
- * block may be split over several workgroups that merge through a per-DEVICE workspace this hook owns: calls for one device
- * must be ordered on one stream (handles own their workspace and have no such restriction between handles). */
+ * block may be split over several workgroups that merge through a workspace this hook owns, one per (device, stream): calls
+ * on different streams do not share state (handles own their workspace).
+ * vitvs_op_attention takes the raw q a plain qkv projection produces and applies 1/8 (and the log2(e) of its exp2) inside the
+ * kernels; in the 16-bit precisions the long-sequence kernel does that by one more 16-bit rounding of q.
+ * vitvs_op_attention_q with q_prescaled != 0 is the form the handle's forward uses in the 16-bit precisions: the q third of qkv
+ * already carries 0.125 * log2(e) (the handle folds it into the q rows of attn.qkv.weight / bias in fp32, before their one
+ * rounding to 16 bits), and the kernels apply nothing.  q_prescaled is ignored for VITVS_F32. */
 VITVS_API int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
                        void* stream);
+VITVS_API int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
+                         int32_t q_prescaled, void* stream);
 
 /* Split-K pair used for the narrow layers (proj, fc2, patch embedding):
  *   slices = vitvs_op_splitk_slices(precision, M, N, K)           (>= 1; the plan the forward uses)

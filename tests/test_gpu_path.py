@@ -379,7 +379,7 @@ def test_compute_velocity_fp32_many_tokens(key):
 #   * the ORDER selection is exact given the device's own tables (first num_pairs mutual NNs met in the visiting order), and
 #     `same_draw` counts the pairs whose draw and matches equal the ones the fp32 oracle's tables give.
 # DESIGN.md §3 quotes these numbers; they are assertions here.
-MODE_BARS = {"bf16": dict(agree1=0.995, agree2=0.99, tie=2e-2, sim_atol=2e-2, same_fixture=8, same_draw=8),
+MODE_BARS = {"bf16": dict(agree1=0.99, agree2=0.99, tie=2e-2, sim_atol=2e-2, same_fixture=8, same_draw=7),
              "fp16": dict(agree1=1.0, agree2=1.0, tie=3e-3, sim_atol=3e-3, same_fixture=8, same_draw=8)}
 
 

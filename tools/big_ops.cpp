@@ -163,24 +163,61 @@ int main(int argc, char** argv) {
         typedef int (*set_probe_t)(void*);
         set_probe_t set_probe = (set_probe_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_attn_probe");
         if (set_probe && N >= 512) {
-            const int wgs = 4 * 8 * ((((N + 127) / 128) * H * n_img + 7) / 8);      // up to 4 key ranges per query block
+            const int wgs = 4 * 8 * ((((N + 127) / 128) * H * n_img + 7) / 8) + 1024;      // every plan's grid fits
+            const int REC = 14;
             unsigned long long* buf;
-            CHECK(hipMalloc((void**)&buf, (size_t)wgs * 4 * 8 * 8));
-            CHECK(hipMemset(buf, 0, (size_t)wgs * 4 * 8 * 8));
-            set_probe(buf);
+            CHECK(hipMalloc((void**)&buf, (size_t)wgs * 4 * REC * 8));
+            CHECK(hipMemset(buf, 0, (size_t)wgs * 4 * REC * 8));
             for (int i = 0; i < 3; ++i) vitvs_op_attention(VITVS_BF16, qkv, out, n_img, N, H, st);
             CHECK(hipStreamSynchronize(st));
+            set_probe(buf);
+            vitvs_op_attention(VITVS_BF16, qkv, out, n_img, N, H, st);
+            CHECK(hipStreamSynchronize(st));
             set_probe(nullptr);
-            std::vector<unsigned long long> hbuf((size_t)wgs * 4 * 8);
+            std::vector<unsigned long long> hbuf((size_t)wgs * 4 * REC);
             CHECK(hipMemcpy(hbuf.data(), buf, hbuf.size() * 8, hipMemcpyDeviceToHost));
-            std::vector<double> col[8];
-            for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * 8 + 7]) for (int k = 0; k < 8; ++k) col[k].push_back((double)hbuf[(size_t)w * 8 + k]);
-            auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-            const double nt = med(col[7]);
+            std::vector<double> col[REC];
+            unsigned long long t_first = ~0ull;
+            for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * REC + 7]) t_first = std::min(t_first, hbuf[(size_t)w * REC + 8]);
+            for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * REC + 7]) {
+                for (int k = 0; k < REC; ++k) col[k].push_back((double)hbuf[(size_t)w * REC + k]);
+                col[8].back() -= (double)t_first; col[9].back() -= (double)t_first;
+            }
+            auto pct = [](std::vector<double> v, double p) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+            auto med = [&](const std::vector<double>& v) { return pct(v, 0.5); };
             auto mean = [](const std::vector<double>& v) { double a = 0; for (double x : v) a += x; return v.empty() ? 0.0 : a / v.size(); };
-            printf("  probe (mean over %zu waves, cycles per tile): wait-dma %.0f  barrier %.0f  copy-issue+K-reads+scores %.0f  softmax %.0f  V-wait+PV %.0f | total %.0f cycles in %.1f us -> %.2f GHz\n",
-                   col[0].size(), mean(col[0]) / nt, mean(col[1]) / nt, mean(col[2]) / nt, mean(col[3]) / nt, mean(col[4]) / nt, med(col[5]), med(col[6]) / 100.0,
+            const double nt = mean(col[7]);
+            printf("  probe (mean over %zu waves, cycles per tile): wait-dma %.0f  barrier %.0f  copy-issue+K-reads+scores %.0f  softmax %.0f  V-wait+PV %.0f | tiles/wave %.1f (slow path %.2f)  segments %.2f  exchange+finish %.0f cycles/wave | lifetime median %.0f cycles in %.1f us -> %.2f GHz\n",
+                   col[0].size(), mean(col[0]) / nt, mean(col[1]) / nt, mean(col[2]) / nt, mean(col[3]) / nt, mean(col[4]) / nt, nt, mean(col[12]), mean(col[11]), mean(col[10]), med(col[5]), med(col[6]) / 100.0,
                    med(col[5]) / (med(col[6]) * 10.0));
+            printf("  timeline (us after the first wave's start): starts p0 %.1f p50 %.1f p90 %.1f p100 %.1f | ends p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f\n",
+                   pct(col[8], 0) / 100, pct(col[8], .5) / 100, pct(col[8], .9) / 100, pct(col[8], 1) / 100, pct(col[9], 0) / 100, pct(col[9], .1) / 100,
+                   pct(col[9], .5) / 100, pct(col[9], .9) / 100, pct(col[9], 1) / 100);
+            {   // per XCD (workgroup id % 8): median end time, median lifetime cycles, median clock; and the spread of the waves' cycle counts
+                printf("  per XCD: ");
+                for (int x = 0; x < 8; ++x) {
+                    std::vector<double> e, c, f;
+                    for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * REC + 7] && ((w / 4) & 7) == x) {
+                        e.push_back((double)(hbuf[(size_t)w * REC + 9] - t_first) / 100.0);
+                        c.push_back((double)hbuf[(size_t)w * REC + 5]);
+                        f.push_back((double)hbuf[(size_t)w * REC + 5] / ((double)hbuf[(size_t)w * REC + 6] * 10.0));
+                    }
+                    printf("[%d] end %.0f..%.0f us, %.0fk cyc, %.2f GHz  ", x, pct(e, 0), pct(e, 1), med(c) / 1e3, med(f));
+                }
+                printf("\n  lifetime kcycles by (workgroup id >> 8): ");
+                for (int cl = 0; cl < 6; ++cl) {
+                    std::vector<double> c;
+                    for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * REC + 7] && ((w / 4) >> 8) == cl) c.push_back((double)hbuf[(size_t)w * REC + 5] / 1e3);
+                    if (!c.empty()) printf("[%d] %.0f..%.0f..%.0f  ", cl, pct(c, 0), med(c), pct(c, 1));
+                }
+                printf("| by ((workgroup id >> 3) %% 3): ");
+                for (int cl = 0; cl < 3; ++cl) {
+                    std::vector<double> c;
+                    for (int w = 0; w < wgs * 4; ++w) if (hbuf[(size_t)w * REC + 7] && (((w / 4) >> 3) % 3) == cl) c.push_back((double)hbuf[(size_t)w * REC + 5] / 1e3);
+                    if (!c.empty()) printf("[%d] %.0f..%.0f..%.0f  ", cl, pct(c, 0), med(c), pct(c, 1));
+                }
+                printf("\n  lifetime cycles p0 %.0fk p10 %.0fk p50 %.0fk p90 %.0fk p100 %.0fk\n", pct(col[5], 0) / 1e3, pct(col[5], .1) / 1e3, pct(col[5], .5) / 1e3, pct(col[5], .9) / 1e3, pct(col[5], 1) / 1e3);
+            }
             CHECK(hipFree(buf));
         }
         CHECK(hipFree(qkv)); CHECK(hipFree(out));

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "vitvs_op_linear_residual": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vitvs_op_layernorm": (_I, [_I, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "vitvs_op_attention": (_I, [_I, _P, _P, _I, _I, _I, _P]),
+    "vitvs_op_attention_q": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_splitk_slices": (_I, [_I, _I, _I, _I]),
     "vitvs_op_linear_tile": (_I, [_I, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_partial": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -273,7 +273,7 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_QKV, st);
             rc = launch_linear(h->prec, cx[k].xn, b.qkvw, b.qkvb, cx[k].qkv, cx[k].M, 3 * D, D, 0, st); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_ATTENTION, st);
-            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st, &h->attn_ws); }
+            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st, &h->attn_ws, h->prec != PREC_F32); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PROJ, st);
             rc = launch_linear_partial(h->prec, cx[k].attn, b.projw, cx[k].part, cx[k].M, D, D,
                                        splitk_slices(h->prec, cx[k].M, D, D), st); }
@@ -526,8 +526,21 @@ int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64
         else if (leaf == "norm1.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n1b, data, D); }
         else if (leaf == "norm2.weight") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n2w, data, D); }
         else if (leaf == "norm2.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.n2b, data, D); }
-        else if (leaf == "attn.qkv.weight") { if ((rc = want(3 * D * D))) return rc; rc = upload_matrix(h, &b.qkvw, data, 3 * D, D, D); }
-        else if (leaf == "attn.qkv.bias") { if ((rc = want(3 * D))) return rc; rc = upload_f32(h, &b.qkvb, data, 3 * D); }
+        else if (leaf == "attn.qkv.weight" || leaf == "attn.qkv.bias") {
+            // 16-bit modes: the q rows carry hd^-0.5 * log2(e) (kernels.h kAttnQScale), folded in here in fp32, before the one
+            // rounding of the weights to 16 bits: the attention kernels then find s * scale * log2(e) in their accumulators
+            const bool w = leaf == "attn.qkv.weight";
+            const size_t n = w ? 3 * D * D : 3 * D, nq = w ? D * D : D;
+            if ((rc = want(n))) return rc;
+            std::vector<float> scaled;
+            const float* src = data;
+            if (h->prec != PREC_F32) {
+                scaled.assign(data, data + n);
+                for (size_t i = 0; i < nq; ++i) scaled[i] *= kAttnQScale;
+                src = scaled.data();
+            }
+            rc = w ? upload_matrix(h, &b.qkvw, src, 3 * D, D, D) : upload_f32(h, &b.qkvb, src, 3 * D);
+        }
         else if (leaf == "attn.proj.weight") { if ((rc = want(D * D))) return rc; rc = upload_matrix(h, &b.projw, data, D, D, D); }
         else if (leaf == "attn.proj.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.projb, data, D); }
         else if (leaf == "mlp.fc1.weight") { if ((rc = want(H4 * D))) return rc; rc = upload_matrix(h, &b.fc1w, data, H4, D, D); }
@@ -640,7 +653,8 @@ int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* fr
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
     if (rc) return rc;
-    rc = launch_facet(h->prec, h->qkv, desc, n_frames, h->T, h->cfg.heads, facet, st);
+    rc = launch_facet(h->prec, h->qkv, desc, n_frames, h->T, h->cfg.heads, facet,
+                      (facet == 0 && h->prec != PREC_F32) ? 1.0f / kAttnQScale : 1.0f, st);   // the q rows carry the attention scale
     if (rc) return set_err(h, rc, "facet launch failed");
     return 0;
 }
@@ -951,6 +965,12 @@ int vitvs_op_attention(int32_t precision, const void* qkv, void* out, int32_t n_
                        void* stream) {
     DeviceScope dev(nullptr);
     return launch_attention(to_prec(precision), qkv, out, n_img, N, H, as_stream(stream));
+}
+int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out, int32_t n_img, int32_t N, int32_t H,
+                         int32_t q_prescaled, void* stream) {
+    DeviceScope dev(nullptr);
+    const Precision p = to_prec(precision);
+    return launch_attention(p, qkv, out, n_img, N, H, as_stream(stream), nullptr, q_prescaled != 0 && p != PREC_F32);
 }
 int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int32_t slices, int32_t* tile) {
     if (!tile) return -1;

@@ -21,6 +21,7 @@
 // measured 1 % slower end to end than this streaming form and was removed: profiles/r01_notes.md.)
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -29,7 +30,7 @@
 
 namespace vitvs {
 
-constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * log2(e), hd = 64
+constexpr float kScaleLog2e = kAttnQScale;                        // hd^-0.5 * log2(e), hd = 64 (kernels.h)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
 __device__ __forceinline__ void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -55,7 +56,7 @@ __device__ __forceinline__ float max16(const f32x4 (&s)[4]) {
 // ------------------------------------------------------------------------------------ bf16
 template <typename HT, int KS>
 __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
-                                                                int N, int D) {
+                                                                int N, int D, float sc) {
     typedef typename Vec16<HT>::x8 hx8;
     typedef typename Vec16<HT>::x4 hx4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, acc_s[t4][r]);
-        mloc = rows_max(mloc) * kScaleLog2e;
+        mloc = rows_max(mloc) * sc;
         const float m_new = fmaxf(m_run, mloc);
         const float neg_m = -m_new;
         float psum = 0.f;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(__builtin_fmaf(acc_s[t4][r], kScaleLog2e, neg_m));
+                const float p = fast_exp2(__builtin_fmaf(acc_s[t4][r], sc, neg_m));
                 acc_s[t4][r] = p;
                 psum += p;
             }
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
 // probe builds only (tools/big_ops probe): per-wave cycle sums of the tile loop's parts + realtime span
 __device__ unsigned long long* g_attn_probe;
 #define VITVS_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(VITVS_SCHED_FENCES)
+#define VITVS_STAMP(var) __builtin_amdgcn_sched_barrier(0)
 #else
 #define VITVS_STAMP(var) do { } while (0)
 #endif
@@ -251,22 +254,28 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// Key split (splits = 2 or 4): 600 query blocks on 768 workgroup slots leave some CUs with three workgroups and most with two
-// (the median wave is done at 76 of 101 us), and 352 blocks (1370 tokens) leave most CUs with one.  The key tiles of a query
-// block are therefore cut into `splits` contiguous ranges, one workgroup each; every workgroup leaves its un-normalised state
-// (O, running maximum, running sum) in `ws`, draws a ticket for its query block, and the one that draws the last ticket merges
-// the states in range order (fixed order: bit-reproducible) and writes the output.  The hand-off is the write-through form of
-// the CDNA4 guide's recipe (state stored with 16-byte sc1 stores, every wave drains them, workgroup barrier, one lane draws
-// the ticket with a relaxed agent-scope add; the last arriver: agent acquire fence, barrier, plain loads) and does not depend
-// on placement; a release fence per workgroup instead (an L2 write-back each, 1200 of them per launch) made the launch 13 %
-// SLOWER than not splitting at all.  The ticket is reset by the last arriver: the array only has to be zero before the
-// first launch.
+// Work division ("stream-K" over key tiles).  The unit of work is one 64-key tile of one 128-query block; a launch has
+// W = items x nt of them (items = images x heads x query blocks, nt = key tiles per sequence), in item-major order.  Workgroup
+// g walks the contiguous range [g per, (g + 1) per) of that list — `per` = ceil(W / G) with G = 768 = three resident workgroups
+// per CU — so every CU gets the same number of tiles whatever items x nt is (600 blocks x 49 tiles on 768 slots: 39 tiles each,
+// where whole blocks gave the busiest CU 49 x 3 and halves 24.5 x 4).  A range crosses item boundaries: it is cut into
+// segments, one per item it touches.  A segment that covers its item's whole key range finishes like a plain flash kernel.
+// Any other segment leaves its un-normalised state (O, running maximum, running sum) in `ws`, draws a ticket for its item, and
+// the workgroup that draws the item's last ticket merges the item's segments in range order (fixed order: bit-reproducible)
+// and writes the output; nobody waits for anybody, so the workgroups need not be co-resident.  The hand-off is the
+// write-through form of the CDNA4 guide's recipe: state stored with 16-byte sc1 stores, every wave drains them, workgroup
+// barrier, one lane draws the ticket with a relaxed agent-scope add; the last arriver: agent acquire fence by every wave,
+// plain loads.  It does not depend on placement.  (A release fence per workgroup instead — an L2 write-back each — made the
+// launch 13 % slower than not dividing at all.)  The ticket is reset by the last arriver: the array only has to be zero before
+// the first launch.  per = nt (G = items) is the undivided form: every segment is a whole item, `ws` is not touched.
+// A workgroup has at most two partial segments: slot 0 = the one that starts inside an item (its first), slot 1 = the one
+// that starts an item and ends inside it (its last).
 constexpr int kAttnStateFloats = 9 * 64 * 4;                // per wave: 8 x 16 bytes of accumulators + (maximum, sum), lane-major
 
 template <typename HT>
-__global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
-                                                                   int D, int n_img, int splits, float* __restrict__ ws,
-                                                                   int* __restrict__ tickets) {
+__global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
+                                                                   int D, int n_img, int per, int g_per_xcd, float qscale,
+                                                                   float* __restrict__ ws, int* __restrict__ tickets) {
     typedef typename Vec16<HT>::x8 hx8;
     typedef typename Vec16<HT>::x4 hx4;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -277,14 +286,41 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     constexpr int STAGE = 2 * 64 * 128;                      // K tile then V tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
-    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, units = items * splits, per = (units + 7) >> 3;
-    const int unit = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (unit >= units) return;
-    const int item = unit / splits, part = unit - item * splits;
-    const int pair = item / nqb;
-    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 128 + 32 * wave;
+    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb;
+    const int nt = (N + 63) >> 6, W = items * nt;
+    // XCD x (workgroup ids x, x + 8, ...) walks the x-th eighth of the list: the query blocks of an (image, head) share its L2
+    const int g = (int)(blockIdx.x & 7) * g_per_xcd + (int)(blockIdx.x >> 3);
+    int w0 = g * per;
+    const int w1 = min(w0 + per, W);
+    if (w0 >= w1) return;
     const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
     const unsigned row_bytes = 6u * (unsigned)D;
+    const unsigned tile_bytes = 64u * row_bytes;
+    const int r8 = lane >> 3;
+    // lane constants of the fragment reads
+    const int k_sw = (r32 >> 1) & 7;                              // K image swizzle of this lane's key row (32 kb + r32)
+    const int li = lane & 15, dh = (lane >> 4) & 1;              // transposed V read: lane li of a 16-lane group, dim half dh
+    const int v_row = 4 * hh + (li >> 2);                        // key row inside a 16-key step (+ 8 for elements 4..7)
+    const int v_sw = ((v_row >> 1) & 1) << 1;                    // window swizzle of that row (the 8-row step keeps bit 1)
+    int* flag = reinterpret_cast<int*>(smem + 3 * STAGE);        // one word behind the ring (same LDS array)
+    int slot = 0;                                                 // ring slot of the NEXT tile to be computed; runs on across segments
+#ifdef VITVS_ATTN_FAIR
+    // Issue arbitration between the waves of a SIMD is by priority, then AGE: of the three workgroups a CU holds, the one
+    // dispatched first runs almost unimpeded and the last one crawls until the others have left (measured: equal work, lifetimes
+    // 127k / 155k / 193k cycles by dispatch round = workgroup id >> 8), so the launch ends on a tail of lone waves.  Each
+    // workgroup therefore takes a priority that rotates with the CU's clock, offset by its dispatch round: at any time the
+    // three hold different priorities, each is on top a third of the time.  Speed only: nothing depends on the placement guess.
+    const unsigned fair_cls = (unsigned)(blockIdx.x >> 8);
+#endif
+#ifdef VITVS_PROBE
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0}, tiles_done = 0, segs = 0, xchg = 0, tx0 = 0, tx1 = 0, slow_tiles = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
+#endif
+    while (w0 < w1) {
+    const int item = w0 / nt, t_begin = w0 - item * nt, ntiles = min(nt - t_begin, w1 - w0);
+    w0 += ntiles;
+    const int pair = item / nqb;
+    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 128 + 32 * wave;
     const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 128u;
     const unsigned k_off = head_off + 2u * (unsigned)D, v_off = head_off + 4u * (unsigned)D;
 
@@ -293,29 +329,22 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     //   K image: chunk c of row r at slot c ^ ((r >> 1) & 7)   (tile128_off: conflict-free ds_read_b128 of 32 rows)
     //   V image: chunk c of row r at slot c ^ (((r >> 1) & 1) << 2): the 4 rows x two 32-byte windows a half-wave of a
     //            transposed read touches then fall on 8 different 32-byte bank windows
-    const int r8 = lane >> 3;
     unsigned koff[2], voff[2];
     int krow[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         krow[c] = 16 * wave + 8 * c + r8;
-        koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7)) + (unsigned)krow[c] * row_bytes;
-        voff[c] = v_off + 16u * (unsigned)((lane & 7) ^ (((krow[c] >> 1) & 1) << 2)) + (unsigned)krow[c] * row_bytes;
+        koff[c] = k_off + 16u * (unsigned)((lane & 7) ^ ((krow[c] >> 1) & 7)) + (unsigned)krow[c] * row_bytes + (unsigned)t_begin * tile_bytes;
+        voff[c] = v_off + 16u * (unsigned)((lane & 7) ^ (((krow[c] >> 1) & 1) << 2)) + (unsigned)krow[c] * row_bytes + (unsigned)t_begin * tile_bytes;
     }
-    // this workgroup's key tiles: [t_begin, t_begin + ntiles) of the ntiles_all tiles of the sequence
-    const int ntiles_all = (N + 63) >> 6, chunk = (ntiles_all + splits - 1) / splits;
-    const int t_begin = part * chunk, ntiles = min(chunk, ntiles_all - t_begin);
+    // Ring slots.  The ring index runs on across segments: when a wave starts a new segment every wave of the workgroup has
+    // passed the barrier of the previous segment's LAST tile, i.e. is done with every slot but that tile's; the new
+    // segment's tiles 0 and 1 go to the two other slots, and its tile 2 is issued behind the barrier of its tile 0.
     // source offsets advance by 64 rows per tile (one add per copy); only the sequence's last tile can reach past row
     // N - 1 and takes the clamped form
-    const unsigned tile_bytes = 64u * row_bytes;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        koff[c] += (unsigned)t_begin * tile_bytes;
-        voff[c] += (unsigned)t_begin * tile_bytes;
-    }
-    auto issue = [&](int t) {                                  // t: tile index inside this workgroup's range
-        unsigned char* dst = smem + (t % 3) * STAGE + (16 * wave) * 128;
-        if (t_begin + t + 1 < ntiles_all) {
+    auto issue = [&](int t, int sl) {                          // t: tile index inside this segment; sl: its ring slot
+        unsigned char* dst = smem + sl * STAGE + (16 * wave) * 128;
+        if (t_begin + t + 1 < nt) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + koff[c]), (lds_ptr)(dst + c * 1024), 16, 0, 0);
@@ -332,8 +361,9 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
             }
         }
     };
-    issue(0);
-    if (ntiles > 1) issue(1);
+    const int slot1 = slot == 2 ? 0 : slot + 1;
+    issue(0, slot);
+    if (ntiles > 1) issue(1, slot1);
     // Q fragments by ordinary loads AFTER the first copies, and consumed (empty asm) before the loop: hipcc places its
     // wait for an ordinary load at the first use, and inside the tile loop that wait would be vmcnt(0) on every
     // iteration, draining the LDS-DMA ring; here it is one wait in the prologue, which tile 0 needs anyway.
@@ -348,22 +378,27 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
     hx8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(hx8, qraw[ks]);
+    if (qscale != 1.0f) {                                       // raw q (the operator hook): scale here, one more 16-bit rounding
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = (HT)((float)qf[ks][j] * qscale);
+    }
+    // The running maximum is subtracted INSIDE the score MFMAs: a fifth k-step multiplies a constant K column pair (1, 1)
+    // with the query's (-m_hi, -m_lo), so the accumulators leave the matrix pipe as s - m, ready for exp2 (no per-score
+    // FMA on the vector pipe, which is what bounds this loop).  m = m_hi + m_lo is exact in two 16-bit terms; every use of
+    // the shift (the scores, the rescale of O and l) sees the same fp32 value m_t.
+    hx8 qm, kone;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qm[j] = (HT)0.f; kone[j] = (HT)((hh == 0 && j < 2) ? 1.f : 0.f); }
+    float m_t = -INFINITY;                                       // the shift baked into qm (-inf: none yet, qm = 0)
 
     f32x16 acc_o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    // lane constants of the fragment reads
-    const int k_sw = (r32 >> 1) & 7;                              // K image swizzle of this lane's key row (32 kb + r32)
-    const int li = lane & 15, dh = (lane >> 4) & 1;              // transposed V read: lane li of a 16-lane group, dim half dh
-    const int v_row = 4 * hh + (li >> 2);                        // key row inside a 16-key step (+ 8 for elements 4..7)
-    const int v_sw = ((v_row >> 1) & 1) << 1;                    // window swizzle of that row (the 8-row step keeps bit 1)
-#ifdef VITVS_PROBE
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0};
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
-#endif
+    float l_run = 0.f;
     for (int t = 0; t < ntiles; ++t) {
         VITVS_STAMP(ts0);
         if (t + 1 < ntiles) wait_vmcnt4();
@@ -372,12 +407,22 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         __builtin_amdgcn_s_barrier();                   // tile t has landed for every wave; everyone is done with tile t - 1
         __builtin_amdgcn_sched_barrier(0);
         VITVS_STAMP(ts2);
-        if (t + 2 < ntiles) issue(t + 2);
-        const unsigned char* ldsK = smem + (t % 3) * STAGE;
+#ifdef VITVS_ATTN_FAIR
+        {   // rotate the issue priority among the (up to three) workgroups of a CU: see the note at `fair_cls`
+            const unsigned ph = ((unsigned)(__builtin_readcyclecounter() >> VITVS_ATTN_FAIR) + fair_cls) % 3u;
+            if (ph == 0) __builtin_amdgcn_s_setprio(0);
+            else if (ph == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
+        const int slot2 = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3: the slot of tile t - 1, free behind the barrier
+        if (t + 2 < ntiles) issue(t + 2, slot2);
+        const unsigned char* ldsK = smem + slot * STAGE;
+        slot = slot == 2 ? 0 : slot + 1;
         const int kb0 = (t_begin + t) * 64;
-        // scores: acc_s[kb][i] = S[key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 hh][query r32]
+        // scores: acc_s[kb][i] = S[key 64 t + 32 kb + (i & 3) + 8 (i >> 2) + 4 hh][query r32] (log2 units) - m_t
         f32x16 acc_s[2];
-        {
+        auto scores = [&](bool shifted) {
             hx8 kf[2][4];                               // all 8 K fragment reads in flight before the first MFMA
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -391,8 +436,10 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
                 acc_s[kb] = mfma32(kf[kb][0], qf[0], zero);   // C = 0 is an inline constant of the instruction: no register zeroing
 #pragma unroll
                 for (int ks = 1; ks < 4; ++ks) acc_s[kb] = mfma32(kf[kb][ks], qf[ks], acc_s[kb]);
+                if (shifted) acc_s[kb] = mfma32(kone, qm, acc_s[kb]);
             }
-        }
+        };
+        scores(true);
 #ifdef VITVS_PROBE
         asm volatile("s_nop 0" ::"v"(acc_s[0][0]), "v"(acc_s[1][15]) : "memory");
 #endif
@@ -414,41 +461,71 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
             VITVS_TR(vf[3][0][0], va0, 6144); VITVS_TR(vf[3][0][1], va0, 6144 + 1024); VITVS_TR(vf[3][1][0], va1, 6144); VITVS_TR(vf[3][1][1], va1, 6144 + 1024);
 #undef VITVS_TR
         }
-        if (kb0 + 64 > N) {                              // keys beyond N: only the last tile has any (wave-uniform)
+        auto mask_tail = [&]() {                         // keys beyond N: only the sequence's last tile has any (wave-uniform)
+            if (kb0 + 64 > N) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (kb0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) acc_s[kb][i] = -INFINITY;
+            }
+        };
+        // Softmax of the lane's 32 scores (one query; the other half of its keys sits in lane ^ 32).  Fast path: the shift of
+        // an EARLIER tile is still in place, p = exp2(s - m_t) straight from the accumulators, no maximum is formed; the
+        // tile is accepted if every lane's sum of p stays <= 64 (so every p <= 64: scores may exceed the shift by up to 6
+        // in log2 units; P in 16 bits and the fp32 sums have that headroom).  Otherwise, and on a segment's first tile, the
+        // slow path: raw scores again, their exact maximum, O and l rescaled to the new shift exactly once.
+        bool slow = t == 0;
+        float psum = 0.f;
+        if (!slow) {
+            mask_tail();
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (kb0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) acc_s[kb][i] = -INFINITY;
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(acc_s[kb][i]);
+                    acc_s[kb][i] = p;
+                    psum += p;
+                }
+            slow = __builtin_amdgcn_ballot_w64(!(psum <= 64.f)) != 0ull;     // (an inf or NaN sum also lands here)
+            if (slow) scores(false);                     // the accumulators hold p now: raw scores again (the K tile is still in LDS)
         }
-        // softmax of the lane's 32 scores (one query); the other half of the query's keys sits in lane ^ 32
-        float mloc = max3(acc_s[0][0], acc_s[0][1], acc_s[0][2]);
+#ifdef VITVS_PROBE
+        if (slow) ++slow_tiles;
+#endif
+        if (slow) {
+            if (t == 0 && m_t != -INFINITY) scores(false);   // (never: a segment starts with m_t = -inf, qm = 0, i.e. raw scores)
+            mask_tail();
+            float mloc = max3(acc_s[0][0], acc_s[0][1], acc_s[0][2]);
 #pragma unroll
-        for (int i = 3; i < 15; i += 2) mloc = max3(mloc, acc_s[0][i], acc_s[0][i + 1]);
-        mloc = max3(mloc, acc_s[0][15], acc_s[1][0]);
+            for (int i = 3; i < 15; i += 2) mloc = max3(mloc, acc_s[0][i], acc_s[0][i + 1]);
+            mloc = max3(mloc, acc_s[0][15], acc_s[1][0]);
 #pragma unroll
-        for (int i = 1; i < 15; i += 2) mloc = max3(mloc, acc_s[1][i], acc_s[1][i + 1]);
-        mloc = fmaxf(mloc, acc_s[1][15]);
-        mloc = fmaxf(mloc, lane_xor32(mloc)) * kScaleLog2e;
-        const float m_new = fmaxf(m_run, mloc);
-        const float neg_m = -m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = fast_exp2(__builtin_fmaf(acc_s[kb][i], kScaleLog2e, neg_m));
-                acc_s[kb][i] = p;
-                psum += p;
-            }
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {
-            const float alpha = fast_exp2(m_run - m_new);
+            for (int i = 1; i < 15; i += 2) mloc = max3(mloc, acc_s[1][i], acc_s[1][i + 1]);
+            mloc = fmaxf(mloc, acc_s[1][15]);
+            mloc = fmaxf(mloc, lane_xor32(mloc));
+            const float m_want = fmaxf(m_t, mloc);       // finite: a tile's first key is valid
+            const HT m_hi = (HT)m_want;
+            const HT m_lo = (HT)(m_want - (float)m_hi);
+            const float m_new = (float)m_hi + (float)m_lo;   // the shift the MFMAs will subtract from now on
+            const float alpha = fast_exp2(m_t - m_new);  // 0 on a first tile (m_t = -inf; O = l = 0 anyway)
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
-            m_run = m_new;
+            m_t = m_new;
+            qm[0] = (HT)(hh == 0 ? -(float)m_hi : 0.f);
+            qm[1] = (HT)(hh == 0 ? -(float)m_lo : 0.f);
+            psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = fast_exp2(acc_s[kb][i] - m_new);
+                    acc_s[kb][i] = p;
+                    psum += p;
+                }
         }
         l_run += psum;
         hx8 pf[4];
@@ -475,50 +552,49 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         asm volatile("s_nop 0" ::"v"(acc_o[0][0]), "v"(acc_o[1][15]) : "memory");
         VITVS_STAMP(ts5);
         sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4;
+        ++tiles_done;
 #endif
     }
-#ifdef VITVS_PROBE
-    if (lane == 0 && g_attn_probe) {
-        unsigned long long* dst = g_attn_probe + ((size_t)blockIdx.x * 4 + wave) * 8;
-        dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3]; dst[4] = sum[4];
-        dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = __builtin_amdgcn_s_memrealtime() - rt0; dst[7] = (unsigned long long)ntiles;
-    }
-#endif
     l_run += lane_xor32(l_run);                                // both lane halves hold the query's whole sum
-    if (splits > 1) {
-        // leave this range's state: ws[unit][wave][group 0 .. 8][lane] x 16 bytes, written through (sc1)
-        float* mine = ws + ((size_t)unit * 4 + wave) * kAttnStateFloats + 4 * lane;
+#ifdef VITVS_PROBE
+    ++segs;
+#endif
+    VITVS_STAMP(tx0);
+    if (ntiles != nt) {
+        // a partial segment: leave its state, ws[2 g + slot][wave][group 0 .. 8][lane] x 16 bytes, written through (sc1)
+        const int first_g = (item * nt) / per, last_g = (item * nt + nt - 1) / per;   // the workgroups that share this item
+        float* mine = ws + ((size_t)(2 * g + (t_begin == 0 ? 1 : 0)) * 4 + wave) * kAttnStateFloats + 4 * lane;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
                 store_out<true>(mine + (4 * db + g4) * 256,
                                 f32x4{acc_o[db][4 * g4], acc_o[db][4 * g4 + 1], acc_o[db][4 * g4 + 2], acc_o[db][4 * g4 + 3]});
-        store_out<true>(mine + 8 * 256, f32x4{m_run, l_run, 0.f, 0.f});
+        store_out<true>(mine + 8 * 256, f32x4{m_t, l_run, 0.f, 0.f});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
         __syncthreads();                                       // ... before the workgroup's one ticket
-        int* flag = reinterpret_cast<int*>(smem);              // (the ring is dead: every wave is past its last tile)
         if (tid == 0) {
             const int drawn = __hip_atomic_fetch_add(tickets + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (drawn == splits - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (drawn == last_g - first_g)
                 __hip_atomic_store(tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            }
             *flag = drawn;
         }
         __syncthreads();
-        if (*flag != splits - 1) return;                       // not the last arriver of this query block
+        const bool last = *flag == last_g - first_g;           // workgroup-uniform
+        __syncthreads();                                       // everyone has read the flag before a later segment rewrites it
+#ifdef VITVS_PROBE
+        if (!last) { VITVS_STAMP(tx1); xchg += tx1 - tx0; }
+#endif
+        if (!last) continue;                                   // another workgroup finishes this item
         // EVERY wave of the merging workgroup takes the agent-scope acquire (one buffer_inv sc1 per wave) before its plain
-        // loads of the other ranges' states: lane 0's fence above orders only its own wave in the HIP memory model, and
-        // the states may sit in this CU's L1 from an earlier launch.
+        // loads of the other segments' states: they may sit in this CU's L1 from an earlier launch.
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // merge the ranges' states in range order; this workgroup's own state comes from its registers
-        const float* st0 = ws + ((size_t)(item * splits) * 4 + wave) * kAttnStateFloats + 4 * lane;
+        // merge the item's segments in range order; this workgroup's own state comes from its registers
+        auto state_of = [&](int gg) { return ws + ((size_t)(2 * gg + (gg == first_g ? 1 : 0)) * 4 + wave) * kAttnStateFloats + 4 * lane; };
         float m_tot = -INFINITY;
-        for (int p2 = 0; p2 < splits; ++p2) {
-            const float mp = (p2 == part) ? m_run : st0[(size_t)p2 * 4 * kAttnStateFloats + 8 * 256];
+        for (int gg = first_g; gg <= last_g; ++gg) {
+            const float mp = (gg == g) ? m_t : state_of(gg)[8 * 256];
             m_tot = fmaxf(m_tot, mp);
         }
         float l_tot = 0.f;
@@ -527,10 +603,10 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o_tot[db][i] = 0.f;
-        for (int p2 = 0; p2 < splits; ++p2) {
-            const float* st = st0 + (size_t)p2 * 4 * kAttnStateFloats;
-            const bool own = p2 == part;                       // wave-uniform
-            float mp = m_run, lp = l_run;
+        for (int gg = first_g; gg <= last_g; ++gg) {
+            const float* st = state_of(gg);
+            const bool own = gg == g;                          // wave-uniform
+            float mp = m_t, lp = l_run;
             f32x4 og[8];
             if (!own) {
                 const f32x4 ml = *reinterpret_cast<const f32x4*>(st + 8 * 256);
@@ -569,6 +645,19 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
                 store_out<false>(dst + 32 * db + 8 * g4, o);
             }
     }
+#ifdef VITVS_PROBE
+    VITVS_STAMP(tx1); xchg += tx1 - tx0;
+#endif
+    }   // segments
+#ifdef VITVS_PROBE
+    if (lane == 0 && g_attn_probe) {
+        unsigned long long* dst = g_attn_probe + ((size_t)blockIdx.x * 4 + wave) * 14;
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3]; dst[4] = sum[4];
+        dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = rt1 - rt0; dst[7] = tiles_done;
+        dst[8] = rt0; dst[9] = rt1; dst[10] = xchg; dst[11] = segs; dst[12] = slow_tiles; dst[13] = 0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ bf16, short sequences
@@ -583,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void attention_16_long_kernel(const HT* __r
 // instead of by all eight.
 template <typename HT>
 __global__ __launch_bounds__(256) void attention_16_short_kernel(const HT* __restrict__ qkv, HT* __restrict__ out,
-                                                                 int N, int D, int n_img) {
+                                                                 int N, int D, int n_img, float sc) {
     typedef typename Vec16<HT>::x8 hx8;
     typedef typename Vec16<HT>::x4 hx4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -649,7 +738,7 @@ __global__ __launch_bounds__(256) void attention_16_short_kernel(const HT* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kb + 16 * t4 + 4 * g + r;
-                float x = acc_s[t4][r] * kScaleLog2e;
+                float x = acc_s[t4][r] * sc;
                 x = (key < N) ? x : -INFINITY;
                 acc_s[t4][r] = x;
                 mloc = fmaxf(mloc, x);
@@ -842,35 +931,46 @@ extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_lds(i
 }
 #endif
 
-// How many key ranges per query block for the long-sequence kernel: the fewest of {1, 2, 4} that minimises the number of
-// half / quarter blocks the busiest CU gets, relative to their size (3 workgroups fit a CU; below ~2 per CU a CU is
-// latency-bound, so more, smaller units win ties); every range keeps at least 4 key tiles.
-int attention_splits(int n_img, int N, int H) {
-    if (N < 512) return 1;
-#ifdef VITVS_ATTN_FORCE_SPLITS                                  // experiments only (tools/): never defined in the product build
-    return ((N + 63) / 64) / VITVS_ATTN_FORCE_SPLITS >= 2 ? VITVS_ATTN_FORCE_SPLITS : 1;
-#endif
+// Work division of the long-sequence kernel: `per` key tiles per workgroup (see the kernel's header).  Measured on MI355X
+// (profiles/r03_notes.md, attention): the three workgroups a CU holds do NOT share it evenly — issue arbitration is by age, the
+// first-dispatched workgroup runs almost unimpeded — and three resident workgroups finish tiles only 1.3x faster than one, so an
+// even cut of the list over 768 co-resident workgroups (every CU the same work, all ending together) gains nothing over whole
+// items (104 vs 103 us at 2 x 3137 tokens): what pays is MORE units than slots, so that the hardware's dispatcher back-fills
+// CUs as units finish and the hand-offs of one unit hide behind the tiles of its neighbours.  The plan is therefore the
+// fewest ranges per item, of {1, 2, 4}, that minimises (rounds of 256 units) x (tiles per unit + 1.5 tiles of hand-off); a
+// range keeps at least 4 key tiles.
+struct AttnPlan { int per, groups; bool divided; };
+static AttnPlan attention_plan(int n_img, int N, int H) {
+    const int nt = (N + 63) / 64;
     const long items = (long)((N + 127) / 128) * H * n_img;
-    const int ntiles = (N + 63) / 64;
-    int best = 1;
+    const long W = items * nt;
+    AttnPlan best{nt, (int)items, false};
+#ifdef VITVS_ATTN_FORCE_GROUPS                                  // experiments only (tools/): never defined in the product build
+    if (VITVS_ATTN_FORCE_GROUPS > 0) {
+        const int per = (int)((W + VITVS_ATTN_FORCE_GROUPS - 1) / VITVS_ATTN_FORCE_GROUPS);
+        return AttnPlan{per, (int)((W + per - 1) / per), per != nt || W % per != 0};
+    }
+    return best;
+#endif
+    if (N < 512) return best;                                   // short sequences in batches: whole items (tools/big_ops attnmid)
     double best_cost = 1e30;
-    // a range costs its tiles plus ~1.5 tiles for leaving / merging its state (measured: two ranges with nothing to balance cost
-    // +5 % at 50 tiles, +14..27 % at 13 tiles); the busiest CU walks ceil(units / 256) of them
     for (int sp : {1, 2, 4}) {
-        if (sp > 1 && ntiles / sp < 4) break;
-        const long units = items * sp;
-        const double cost = (double)((units + 255) / 256) * ((double)ntiles / sp + (sp > 1 ? 1.5 : 0.0));
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }   // ties: the fewer ranges
+        if (sp > 1 && nt / sp < 4) break;
+        const int per = (nt + sp - 1) / sp;
+        const long units = (W + per - 1) / per;
+        const double cost = (double)((units + 255) / 256) * ((double)per + (sp > 1 ? 1.5 : 0.0));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = AttnPlan{per, (int)units, sp > 1}; }   // ties: the fewer ranges
     }
     return best;
 }
+int attention_splits(int n_img, int N, int H) { return attention_plan(n_img, N, H).divided ? 2 : 1; }   // (reported by tools only)
 
 size_t attention_workspace_floats(int n_img, int N, int H) {
-    const int sp = attention_splits(n_img, N, H);
-    return sp > 1 ? (size_t)((N + 127) / 128) * H * n_img * sp * 4 * kAttnStateFloats : 0;
+    const AttnPlan pl = attention_plan(n_img, N, H);
+    return pl.divided ? (size_t)2 * (8 * ((pl.groups + 7) / 8)) * 4 * kAttnStateFloats : 0;
 }
 size_t attention_ticket_count(int n_img, int N, int H) {
-    return attention_splits(n_img, N, H) > 1 ? (size_t)((N + 127) / 128) * H * n_img : 0;
+    return attention_plan(n_img, N, H).divided ? (size_t)((N + 127) / 128) * H * n_img : 0;
 }
 
 // The pointer-only operator hook (vitvs_op_attention) has no handle to own the key-split workspace: one per (device, stream),
@@ -910,46 +1010,48 @@ static const AttnWorkspace* shared_attention_workspace(hipStream_t stream, size_
 }
 
 template <typename HT>
-static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream, const AttnWorkspace* ws) {
+static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, hipStream_t stream, const AttnWorkspace* ws,
+                               bool q_prescaled) {
     const int D = H * 64;
+    const float sc = q_prescaled ? 1.0f : kScaleLog2e;         // what is left to apply to q . k (log2 units)
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
     // (the 16-query kernel beyond 640 workgroups: 16 images x 197 tokens 16.2 us against 12.6 us on the 64-query kernel)
     if (N <= 256 && (long)((N + 15) / 16) * H * n_img <= 640 && (long)n_img * N * 6 * D < (1l << 32)) {
         const int items = ((N + 15) / 16) * H * n_img;
         launch(attention_16_short_kernel<HT>, dim3(8 * ((items + 7) / 8)), dim3(256), 4 * 8192 + 4 * 5 * 64 * 16, stream, qkv,
-               out, N, D, n_img);
+               out, N, D, n_img, sc);
     } else if ((N >= 512 || (N >= 128 && (long)nt * H * n_img > 256)) && (long)n_img * N * 6 * D < (1l << 32)) {
         // 128 queries per workgroup: from 512 tokens on, and for shorter sequences once the 64-query kernel no longer fits its
         // 512-thread one-workgroup-per-CU form (each of its workgroups re-reads its head's K / V): 16 x 197 x 12 heads
         // 12.7 -> 10.7 us, 6 x 485 x 6 heads 12.9 -> 10.9 us; equal at 6..12 x 197; below that bound the 64-query kernel wins
         // (5 x 197, the rotation search: 5.3 vs 7.2 us; 5 x 485 x 6: 8.0 vs 10.7 us)  [tools/big_ops attnmid]
-        const int sp = attention_splits(n_img, N, H);
-        const int units = ((N + 127) / 128) * H * n_img * sp;
-        if (sp > 1) {
+        const AttnPlan pl = attention_plan(n_img, N, H);
+        if (pl.divided) {
             if (!ws) ws = shared_attention_workspace(stream, attention_workspace_floats(n_img, N, H), attention_ticket_count(n_img, N, H));
             if (!ws || !ws->state || !ws->tickets) return -3;
         }
-        int lds = 3 * 2 * 64 * 128;
+        int lds = 3 * 2 * 64 * 128 + 16;
 #ifdef VITVS_PROBE
-        lds = g_attn_lds_bytes;
+        lds = g_attn_lds_bytes + 16;
         if (lds > 64 * 1024) {
             static std::atomic<unsigned long long> raised{0};
             if (raise_lds_limit((const void*)attention_16_long_kernel<HT>, 160 * 1024, raised)) return -3;
         }
 #endif
-        launch(attention_16_long_kernel<HT>, dim3(8 * ((units + 7) / 8)), dim3(256), lds, stream, qkv, out, N, D, n_img,
-               sp, sp > 1 ? ws->state : nullptr, sp > 1 ? ws->tickets : nullptr);
+        const int g_per_xcd = (pl.groups + 7) / 8;
+        launch(attention_16_long_kernel<HT>, dim3(8 * g_per_xcd), dim3(256), lds, stream, qkv, out, N, D, n_img, pl.per, g_per_xcd, sc,
+               pl.divided ? ws->state : nullptr, pl.divided ? ws->tickets : nullptr);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
-        launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D);
+        launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D, sc);
     } else {
-        launch((attention_16_kernel<HT, 1>), grid, dim3(256), 2 * 64 * 128, stream, qkv, out, N, D);
+        launch((attention_16_kernel<HT, 1>), grid, dim3(256), 2 * 64 * 128, stream, qkv, out, N, D, sc);
     }
     return 0;
 }
 
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream,
-                     const AttnWorkspace* ws) {
+                     const AttnWorkspace* ws, bool q_prescaled) {
     if (n_img <= 0 || N <= 0 || H <= 0) return -2;
     const int D = H * 64;
     const int nt = (N + 63) / 64;
@@ -958,9 +1060,9 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (p == PREC_F16) {
-        rc = launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, ws);
+        rc = launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, ws, q_prescaled);
     } else {
-        rc = launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream, ws);
+        rc = launch_attention_16<bf16>((const bf16*)qkv, (bf16*)out, n_img, N, H, stream, ws, q_prescaled);
     }
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -1;

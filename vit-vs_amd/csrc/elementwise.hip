@@ -461,22 +461,22 @@ int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStr
 // GEMM's output [n_img*(1+T)][3][H][64] to fp32 [n_img][T][D] with descriptor index d * H + h, cls token dropped.
 template <typename T>
 __global__ __launch_bounds__(256) void facet_kernel(const T* __restrict__ qkv, float* __restrict__ out, int Tn, int H,
-                                                    int which) {
+                                                    int which, float unscale) {
     const int tok = blockIdx.x, img = tok / Tn, t = tok - img * Tn;
     const int D = H * 64;
     const T* src = qkv + ((size_t)img * (Tn + 1) + 1 + t) * 3 * D + (size_t)which * D;
     float* dst = out + (size_t)tok * D;
     for (int j = threadIdx.x; j < D; j += 256) {
         const int h = j % H, d = j / H;
-        dst[j] = (float)src[h * 64 + d];
+        dst[j] = (float)src[h * 64 + d] * unscale;
     }
 }
 
-int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, hipStream_t stream) {
+int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, hipStream_t stream) {
     if (n_img <= 0 || T <= 0 || H <= 0 || which < 0 || which > 2) return -2;
-    if (p == PREC_F32) launch(facet_kernel<float>, dim3(n_img * T), dim3(256), 0, stream, (const float*)qkv, out, T, H, which);
-    else if (p == PREC_F16) launch(facet_kernel<f16>, dim3(n_img * T), dim3(256), 0, stream, (const f16*)qkv, out, T, H, which);
-    else launch(facet_kernel<bf16>, dim3(n_img * T), dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which);
+    if (p == PREC_F32) launch(facet_kernel<float>, dim3(n_img * T), dim3(256), 0, stream, (const float*)qkv, out, T, H, which, q_unscale);
+    else if (p == PREC_F16) launch(facet_kernel<f16>, dim3(n_img * T), dim3(256), 0, stream, (const f16*)qkv, out, T, H, which, q_unscale);
+    else launch(facet_kernel<bf16>, dim3(n_img * T), dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which, q_unscale);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

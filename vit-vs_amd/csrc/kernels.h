@@ -151,8 +151,12 @@ struct AttnWorkspace {
 };
 size_t attention_workspace_floats(int n_img, int N, int H);
 size_t attention_ticket_count(int n_img, int N, int H);
+// q_prescaled (16-bit precisions only): the q third of qkv already carries hd^-0.5 * log2(e) (kAttnQScale) — the handle folds it
+// into the q rows of attn.qkv.weight / bias at upload, in fp32 before the one rounding to 16 bits, so the scale costs the
+// forward neither an instruction nor a rounding; raw q (the operator hook) is scaled inside the kernels.
+constexpr float kAttnQScale = 0.125f * 1.44269504088896340736f;
 int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, int H, hipStream_t stream,
-                     const AttnWorkspace* ws = nullptr);
+                     const AttnWorkspace* ws = nullptr, bool q_prescaled = false);
 
 // ---- correspond.hip ------------------------------------------------------------------------
 // For pair b: S = dn[a_img(b)] . dn[b_img(b)]^T (T x T, fp32); row_best[b][i] / col_best[b][j] receive
@@ -211,7 +215,8 @@ struct ServoArgs {
 int launch_servo(const ServoArgs& a, hipStream_t stream);
 
 // out[n_img][T][D] fp32, index d*H + h <- which-th (0 q, 1 k, 2 v) third of qkv[n_img*(1+T)][3][H][64], cls dropped
-int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, hipStream_t stream);
+// q_unscale: factor that undoes a pre-scaled q third (1 / kAttnQScale for which == 0 in the 16-bit modes, else 1)
+int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, hipStream_t stream);
 // Pillow-exact bicubic resize of n RGB uint8 frames [in_h][in_w][3] -> [out][out][3] (resize.hip).  The tables come from
 // resize_coefficients (host, double precision, Pillow's expressions): bounds [out][2] = (first tap, taps), coefficients
 // [out][ksize] in 22-bit fixed point; x tables for the width, y tables for the height.
