@@ -245,8 +245,6 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
 // probe builds only (tools/big_ops probe): per-wave cycle sums of the tile loop's parts + realtime span
 __device__ unsigned long long* g_attn_probe;
 #define VITVS_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(VITVS_SCHED_FENCES)
-#define VITVS_STAMP(var) __builtin_amdgcn_sched_barrier(0)
 #else
 #define VITVS_STAMP(var) do { } while (0)
 #endif
@@ -304,14 +302,6 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
     const int v_sw = ((v_row >> 1) & 1) << 1;                    // window swizzle of that row (the 8-row step keeps bit 1)
     int* flag = reinterpret_cast<int*>(smem + 3 * STAGE);        // one word behind the ring (same LDS array)
     int slot = 0;                                                 // ring slot of the NEXT tile to be computed; runs on across segments
-#ifdef VITVS_ATTN_FAIR
-    // Issue arbitration between the waves of a SIMD is by priority, then AGE: of the three workgroups a CU holds, the one
-    // dispatched first runs almost unimpeded and the last one crawls until the others have left (measured: equal work, lifetimes
-    // 127k / 155k / 193k cycles by dispatch round = workgroup id >> 8), so the launch ends on a tail of lone waves.  Each
-    // workgroup therefore takes a priority that rotates with the CU's clock, offset by its dispatch round: at any time the
-    // three hold different priorities, each is on top a third of the time.  Speed only: nothing depends on the placement guess.
-    const unsigned fair_cls = (unsigned)(blockIdx.x >> 8);
-#endif
 #ifdef VITVS_PROBE
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0}, tiles_done = 0, segs = 0, xchg = 0, tx0 = 0, tx1 = 0, slow_tiles = 0;
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
@@ -407,14 +397,6 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
         __builtin_amdgcn_s_barrier();                   // tile t has landed for every wave; everyone is done with tile t - 1
         __builtin_amdgcn_sched_barrier(0);
         VITVS_STAMP(ts2);
-#ifdef VITVS_ATTN_FAIR
-        {   // rotate the issue priority among the (up to three) workgroups of a CU: see the note at `fair_cls`
-            const unsigned ph = ((unsigned)(__builtin_readcyclecounter() >> VITVS_ATTN_FAIR) + fair_cls) % 3u;
-            if (ph == 0) __builtin_amdgcn_s_setprio(0);
-            else if (ph == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(2);
-        }
-#endif
         const int slot2 = slot == 0 ? 2 : slot - 1;     // (slot + 2) % 3: the slot of tile t - 1, free behind the barrier
         if (t + 2 < ntiles) issue(t + 2, slot2);
         const unsigned char* ldsK = smem + slot * STAGE;
