@@ -152,6 +152,13 @@ VITVS_API int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, c
  * facet: 0 query, 1 key, 2 value.  In bf16 mode the values carry the qkv GEMM's bf16 output rounding. */
 VITVS_API int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, float* desc,
                             void* stream);
+/* The extractor's whole descriptor surface, extract_descriptors(batch, layer, facet, bin, include_cls)
+ * (dinov2_extractor.py:313-337): facet 0 query, 1 key, 2 value, 3 token; bin != 0: the 3x3 log-bin of that facet (:265-311),
+ * desc fp32 [n][T][9 D]; include_cls != 0: the cls row is kept, desc [n][1 + T][D]; neither: [n][T][D].  bin together with
+ * include_cls is refused like the reference's assertion (error -5).  Independent of cfg.binned (which selects what the
+ * velocity path correlates).  Raw, un-normalised values, like vitvs_extract_descriptors_dev. */
+VITVS_API int vitvs_extract_descriptors_ex_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, int32_t bin,
+                                     int32_t include_cls, float* desc, void* stream);
 /* Residual stream after block `cfg.blocks - 1`, fp32 [n][1+T][D] (what the forward hook captures,
  * dinov2_extractor.py:198-199), for parity tests. */
 VITVS_API int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream);

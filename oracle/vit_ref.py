@@ -120,12 +120,19 @@ def extract_descriptors(sd, frames_u8, *, patch, stride, heads, layer, mean, std
 
 
 @torch.no_grad()
-def extract_facet(sd, frames_u8, *, patch, stride, heads, layer, mean, std, facet: str, eps: float = 1e-6) -> torch.Tensor:
-    """``ViTExtractor.extract_descriptors(facet='query'|'key'|'value', bin=False, include_cls=False)``: [B,1,T,D].
+def extract_facet(sd, frames_u8, *, patch, stride, heads, layer, mean, std, facet: str, eps: float = 1e-6,
+                  bin: bool = False, include_cls: bool = False) -> torch.Tensor:
+    """``ViTExtractor.extract_descriptors(facet='query'|'key'|'value'|'token', bin, include_cls)``: [B,1,T,D], [B,1,1+T,D]
+    with ``include_cls`` or [B,1,T,9D] with ``bin`` (the two together are refused, dinov2_extractor.py:330-331).
 
     dinov2_extractor.py:193-217: the hook on ``blocks[layer].attn`` recomputes ``qkv = attn.qkv(norm1(x))`` reshaped to
     [3,B,H,N,hd] and keeps one of the three ([B,H,N,hd]); :326-334 drops the cls token and flattens with
     ``permute(0,2,3,1)``, i.e. descriptor index = d * H + h (head index fastest)."""
+    assert not (bin and include_cls), "bin = True and include_cls = True are not supported together, set one of them False."
+    if facet == "token":
+        f = block_tokens(sd, frames_u8, patch=patch, stride=stride, heads=heads, layer=layer, mean=mean, std=std, eps=eps)
+        f = f if include_cls else f[:, 1:]
+        return (log_bin(f, int(math.sqrt(f.shape[1]))) if bin else f).unsqueeze(1)
     idx = {"query": 0, "key": 1, "value": 2}[facet]
     stages = block_tokens(sd, frames_u8, patch=patch, stride=stride, heads=heads, layer=layer, mean=mean, std=std,
                           eps=eps, return_all=True)
@@ -136,8 +143,12 @@ def extract_facet(sd, frames_u8, *, patch, stride, heads, layer, mean, std, face
     b, n, c = y.shape
     qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(b, n, 3, heads, c // heads)
     f = qkv.permute(2, 0, 3, 1, 4)[idx]                      # B x H x N x hd
-    f = f[:, :, 1:, :]
-    return f.permute(0, 2, 3, 1).flatten(start_dim=-2, end_dim=-1).unsqueeze(1)
+    if not include_cls:
+        f = f[:, :, 1:, :]
+    f = f.permute(0, 2, 3, 1).flatten(start_dim=-2, end_dim=-1)     # B x t x (d x h)
+    if bin:                                                  # _log_bin on the B x h x t x d tensor: the same 3x3 concatenation
+        f = log_bin(f, int(math.sqrt(f.shape[1])))
+    return f.unsqueeze(1)
 
 
 def log_bin(tokens: torch.Tensor, grid: int) -> torch.Tensor:

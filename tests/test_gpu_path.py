@@ -961,20 +961,34 @@ def test_controller_failure_counter_raises_like_the_reference():
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("layerscale", [False, True])
 def test_extract_descriptors_facets(precision, tol, layerscale):
-    """query / key / value facets (dinov2_extractor.py:193-217, 326-334): layout d*H + h, cls dropped."""
+    """The extractor's descriptor surface (dinov2_extractor.py:193-217, 313-337): every facet, plain (layout d*H + h, cls
+    dropped), with the cls row kept, and log-binned (3x3 neighbourhood of that facet, :265-311); bin with include_cls is
+    refused like the reference's assertion, an unknown facet like its message."""
     cfg = _tiny_cfg(layerscale)
     sd = weights.synthetic_state_dict(cfg, 11, affine_jitter=True)
     eng = _engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision=precision,
                   max_pairs=1).load_state_dict(sd)
     frames = np.stack(synth.frame_pair(cfg.img_size, 4242))
-    for facet in ("query", "key", "value"):
-        ref = vit_ref.extract_facet(sd, frames, patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
-                                    mean=cfg.mean, std=cfg.std, facet=facet)
-        got = eng.extract_descriptors(frames, facet=facet).cpu()
-        assert got.shape == ref.shape == (2, 1, cfg.tokens, cfg.dim)
-        assert float((got - ref).abs().max() / ref.abs().max()) <= tol
+    kw = dict(patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+    for facet in ("query", "key", "value", "token"):
+        for binned, cls in ((False, False), (False, True), (True, False)):
+            ref = vit_ref.extract_facet(sd, frames, facet=facet, bin=binned, include_cls=cls, **kw)
+            got = eng.extract_descriptors(frames, facet=facet, bin=binned, include_cls=cls).cpu()
+            assert got.shape == ref.shape == (2, 1, cfg.tokens + int(cls), cfg.dim * (9 if binned else 1))
+            assert float((got - ref).abs().max() / ref.abs().max()) <= tol, (facet, binned, cls)
+        if facet != "token":      # binning is a pure copy of the plain facet descriptors
+            plain = eng.extract_descriptors(frames, facet=facet).cpu()[:, 0]
+            assert torch.equal(eng.extract_descriptors(frames, facet=facet, bin=True).cpu()[:, 0], vit_ref.log_bin(plain, cfg.grid))
+    with pytest.raises(AssertionError):
+        eng.extract_descriptors(frames, facet="key", bin=True, include_cls=True)
     with pytest.raises(TypeError):
         eng.extract_descriptors(frames, facet="attn")
+    import ctypes as C
+    fr = torch.from_numpy(frames).cuda()
+    out = torch.empty((2, 1, cfg.seq, cfg.dim * 9), dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert eng.lib.vitvs_extract_descriptors_ex_dev(eng.handle, 2, C.c_void_p(fr.data_ptr()), 1, 1, 1, C.c_void_p(out.data_ptr()), st) < 0
+    assert "not supported together" in _lib.last_error(eng.handle)
 
 
 # ----------------------------------------------------------------------------------- size-independent properties

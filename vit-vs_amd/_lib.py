@@ -61,6 +61,7 @@ PROTOTYPES = {
     "vitvs_tokens": (_I, [_P]),
     "vitvs_desc_dim": (_I, [_P]),
     "vitvs_extract_facet_dev": (_I, [_P, _I, _P, _I, _P, _P]),
+    "vitvs_extract_descriptors_ex_dev": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "vitvs_resize_frames_dev": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "vitvs_op_linear": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_variant": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

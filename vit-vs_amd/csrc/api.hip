@@ -647,15 +647,38 @@ int vitvs_extract_descriptors_dev(vitvs_handle* h, int32_t n_frames, const uint8
 
 int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, float* desc,
                             void* stream) {
-    if (!h || !frames || !desc) return set_err(h, -1, "null argument");
     if (facet < 0 || facet > 2) return set_err(h, -5, "facet must be 0 (query), 1 (key) or 2 (value)");
+    return vitvs_extract_descriptors_ex_dev(h, n_frames, frames, facet, 0, 0, desc, stream);
+}
+
+int vitvs_extract_descriptors_ex_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, int32_t bin,
+                                     int32_t include_cls, float* desc, void* stream) {
+    if (!h || !frames || !desc) return set_err(h, -1, "null argument");
+    if (facet < 0 || facet > 3) return set_err(h, -5, "facet must be 0 (query), 1 (key), 2 (value) or 3 (token)");
+    if (bin && include_cls)   // the reference's assertion (dinov2_extractor.py:330-331)
+        return set_err(h, -5, "bin = True and include_cls = True are not supported together, set one of them False.");
     DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
     if (rc) return rc;
-    rc = launch_facet(h->prec, h->qkv, desc, n_frames, h->T, h->cfg.heads, facet,
-                      (facet == 0 && h->prec != PREC_F32) ? 1.0f / kAttnQScale : 1.0f, st);   // the q rows carry the attention scale
-    if (rc) return set_err(h, rc, "facet launch failed");
+    const int T = h->T, D = h->cfg.dim;
+    const float* src = h->x;                                  // token facet: the residual stream itself, [n][1 + T][D]
+    if (facet < 3) {
+        // q / k / v of blocks[layer] in the reference's layout (index d * H + h), fp32, WITH the cls row, over the residual
+        // stream's own buffer (the forward is done with it; any cached goal was dropped by the forward above)
+        rc = launch_facet(h->prec, h->qkv, h->x, n_frames, T, h->cfg.heads, facet,
+                          (facet == 0 && h->prec != PREC_F32) ? 1.0f / kAttnQScale : 1.0f, 1, st);   // the q rows carry the attention scale
+        if (rc) return set_err(h, rc, "facet launch failed");
+    }
+    if (bin) {
+        rc = launch_descriptors(src, nullptr, desc, h->sq, n_frames, T, h->grid, D, 1, nullptr, nullptr, 0, st);
+        if (rc) return set_err(h, rc, "descriptor launch failed");
+    } else if (include_cls) {
+        VITVS_HIP_CHECK(hipMemcpyAsync(desc, src, (size_t)n_frames * (T + 1) * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        VITVS_HIP_CHECK(hipMemcpy2DAsync(desc, (size_t)T * D * sizeof(float), src + D, (size_t)(T + 1) * D * sizeof(float),
+                                         (size_t)T * D * sizeof(float), n_frames, hipMemcpyDeviceToDevice, st));
+    }
     return 0;
 }
 

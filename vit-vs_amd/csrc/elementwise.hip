@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void desc_binned_kernel(const float* __restric
     for (int e = threadIdx.x; e < 9 * D; e += blockDim.x) {
         const int o = e / D, d = e - o * D;
         const float v = x[((size_t)img * (T + 1) + 1 + nb[o]) * D + d];
-        dst[e] = __fdiv_rn(v, nrm);
+        if (dn) dst[e] = __fdiv_rn(v, nrm);
         if (raw) raw[(size_t)tok * 9 * D + e] = v;
     }
 }
@@ -461,10 +461,12 @@ int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStr
 // GEMM's output [n_img*(1+T)][3][H][64] to fp32 [n_img][T][D] with descriptor index d * H + h, cls token dropped.
 template <typename T>
 __global__ __launch_bounds__(256) void facet_kernel(const T* __restrict__ qkv, float* __restrict__ out, int Tn, int H,
-                                                    int which, float unscale) {
-    const int tok = blockIdx.x, img = tok / Tn, t = tok - img * Tn;
+                                                    int which, float unscale, int keep_cls) {
+    // keep_cls = 0: out [n_img][T][D] (cls dropped); 1: out [n_img][1 + T][D]
+    const int rows = Tn + keep_cls;
+    const int tok = blockIdx.x, img = tok / rows, t = tok - img * rows;
     const int D = H * 64;
-    const T* src = qkv + ((size_t)img * (Tn + 1) + 1 + t) * 3 * D + (size_t)which * D;
+    const T* src = qkv + ((size_t)img * (Tn + 1) + (1 - keep_cls) + t) * 3 * D + (size_t)which * D;
     float* dst = out + (size_t)tok * D;
     for (int j = threadIdx.x; j < D; j += 256) {
         const int h = j % H, d = j / H;
@@ -472,11 +474,14 @@ __global__ __launch_bounds__(256) void facet_kernel(const T* __restrict__ qkv, f
     }
 }
 
-int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, hipStream_t stream) {
+int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, int keep_cls,
+                 hipStream_t stream) {
     if (n_img <= 0 || T <= 0 || H <= 0 || which < 0 || which > 2) return -2;
-    if (p == PREC_F32) launch(facet_kernel<float>, dim3(n_img * T), dim3(256), 0, stream, (const float*)qkv, out, T, H, which, q_unscale);
-    else if (p == PREC_F16) launch(facet_kernel<f16>, dim3(n_img * T), dim3(256), 0, stream, (const f16*)qkv, out, T, H, which, q_unscale);
-    else launch(facet_kernel<bf16>, dim3(n_img * T), dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which, q_unscale);
+    const dim3 grid(n_img * (T + (keep_cls ? 1 : 0)));
+    const int kc = keep_cls ? 1 : 0;
+    if (p == PREC_F32) launch(facet_kernel<float>, grid, dim3(256), 0, stream, (const float*)qkv, out, T, H, which, q_unscale, kc);
+    else if (p == PREC_F16) launch(facet_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)qkv, out, T, H, which, q_unscale, kc);
+    else launch(facet_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which, q_unscale, kc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

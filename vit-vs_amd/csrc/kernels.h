@@ -216,7 +216,9 @@ int launch_servo(const ServoArgs& a, hipStream_t stream);
 
 // out[n_img][T][D] fp32, index d*H + h <- which-th (0 q, 1 k, 2 v) third of qkv[n_img*(1+T)][3][H][64], cls dropped
 // q_unscale: factor that undoes a pre-scaled q third (1 / kAttnQScale for which == 0 in the 16-bit modes, else 1)
-int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, hipStream_t stream);
+// keep_cls: 0 -> out [n_img][T][D]; 1 -> out [n_img][1 + T][D] (the cls row first)
+int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, int keep_cls,
+                 hipStream_t stream);
 // Pillow-exact bicubic resize of n RGB uint8 frames [in_h][in_w][3] -> [out][out][3] (resize.hip).  The tables come from
 // resize_coefficients (host, double precision, Pillow's expressions): bounds [out][2] = (first tap, taps), coefficients
 // [out][ksize] in 22-bit fixed point; x tables for the width, y tables for the height.

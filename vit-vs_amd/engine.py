@@ -146,24 +146,32 @@ class Engine:
         self._check(rc, "vitvs_resize_frames_dev")
         return out
 
-    def extract_descriptors(self, frames, facet: str = "token") -> torch.Tensor:
-        """``ViTExtractor.extract_descriptors(..., facet, bin=binned)``: [n,1,T,D'].  facet 'token' (the servo
-        path's choice) or 'query' / 'key' / 'value' (un-binned, [n,1,T,D], index d*H + h like the reference)."""
+    FACETS = ("query", "key", "value", "token")
+
+    def extract_descriptors(self, frames, facet: str = "token", bin: Optional[bool] = None,
+                            include_cls: bool = False) -> torch.Tensor:
+        """``ViTExtractor.extract_descriptors(batch, layer, facet, bin, include_cls)`` (dinov2_extractor.py:313-337):
+        [n,1,T,D], [n,1,T,9D] with ``bin`` (3x3 log-bin of that facet), [n,1,1+T,D] with ``include_cls``.  facet 'token' (the
+        servo path's choice) or 'query' / 'key' / 'value' (descriptor index d*H + h like the reference).  ``bin=None``: the
+        engine's ``use_feature_binning`` for the token facet, False for the others.  ``bin`` with ``include_cls`` raises the
+        reference's AssertionError; an unknown facet its TypeError-like message."""
+        if facet not in self.FACETS:
+            raise TypeError(f"{facet} is not a supported facet.")                # the reference's message
+        binned = (self.binned if facet == "token" else False) if bin is None else bool(bin)
+        if binned and include_cls:
+            raise AssertionError("bin = True and include_cls = True are not supported together, set one of them False.")
         f = self._frames(frames)
         n = f.shape[0]
-        if facet != "token":
-            if facet not in ("query", "key", "value"):
-                raise TypeError(f"{facet} is not a supported facet.")            # the reference's message
-            if self.binned:
-                raise VitvsError("facets other than 'token' are not binned")
-            out = torch.empty((n, 1, self.tokens, self.cfg.dim), dtype=torch.float32, device=self.device)
-            rc = self.lib.vitvs_extract_facet_dev(self.handle, n, _ptr(f), ("query", "key", "value").index(facet), _ptr(out),
-                                                  _stream_ptr(self.device))
-            self._check(rc, "vitvs_extract_facet_dev")
+        if facet == "token" and not include_cls and binned == self.binned:      # the velocity path's own descriptors
+            out = torch.empty((n, 1, self.tokens, self.desc_dim), dtype=torch.float32, device=self.device)
+            rc = self.lib.vitvs_extract_descriptors_dev(self.handle, n, _ptr(f), _ptr(out), _stream_ptr(self.device))
+            self._check(rc, "vitvs_extract_descriptors_dev")
             return out
-        out = torch.empty((n, 1, self.tokens, self.desc_dim), dtype=torch.float32, device=self.device)
-        rc = self.lib.vitvs_extract_descriptors_dev(self.handle, n, _ptr(f), _ptr(out), _stream_ptr(self.device))
-        self._check(rc, "vitvs_extract_descriptors_dev")
+        rows = self.tokens + (1 if include_cls else 0)
+        out = torch.empty((n, 1, rows, self.cfg.dim * (9 if binned else 1)), dtype=torch.float32, device=self.device)
+        rc = self.lib.vitvs_extract_descriptors_ex_dev(self.handle, n, _ptr(f), self.FACETS.index(facet), int(binned),
+                                                       int(include_cls), _ptr(out), _stream_ptr(self.device))
+        self._check(rc, "vitvs_extract_descriptors_ex_dev")
         return out
 
     def correspond(self, desc1: torch.Tensor, desc2: torch.Tensor, want_matrix: bool = False):
