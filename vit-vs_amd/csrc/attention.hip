@@ -568,46 +568,50 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
         if (!last) { VITVS_STAMP(tx1); xchg += tx1 - tx0; }
 #endif
         if (!last) continue;                                   // another workgroup finishes this item
-        // EVERY wave of the merging workgroup takes the agent-scope acquire (one buffer_inv sc1 per wave) before its plain
-        // loads of the other segments' states: they may sit in this CU's L1 from an earlier launch.
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // merge the item's segments in range order; this workgroup's own state comes from its registers
+        // The other segments' states are read with sc1 loads, every byte of them: written through by their producers (sc1
+        // stores, drained by every storing wave before the workgroup's one ticket add), they are in memory, and an sc1 load
+        // does not look in this CU's L1 — the only cache that could hold an older copy (the XCD's L2 was invalidated at
+        // launch start and has not seen these lines since).  This is the CDNA4 guide's "sc1 loads in place of the acquire"
+        // hand-off (one lane of each storing workgroup adds to one counter; the workgroup whose add came last reads, its
+        // other waves behind the barrier above); an agent acquire by every wave instead cost ~2.5 us per merging workgroup
+        // (buffer_inv per wave, three workgroups per CU).  Merged in range order, one pass, this workgroup's own state from
+        // its registers: bit-reproducible.
         auto state_of = [&](int gg) { return ws + ((size_t)(2 * gg + (gg == first_g ? 1 : 0)) * 4 + wave) * kAttnStateFloats + 4 * lane; };
-        float m_tot = -INFINITY;
-        for (int gg = first_g; gg <= last_g; ++gg) {
-            const float mp = (gg == g) ? m_t : state_of(gg)[8 * 256];
-            m_tot = fmaxf(m_tot, mp);
-        }
-        float l_tot = 0.f;
+        float m_tot = -INFINITY, l_tot = 0.f;
         f32x16 o_tot[2];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o_tot[db][i] = 0.f;
         for (int gg = first_g; gg <= last_g; ++gg) {
-            const float* st = state_of(gg);
             const bool own = gg == g;                          // wave-uniform
             float mp = m_t, lp = l_run;
-            f32x4 og[8];
+            u32x4 og[9];
             if (!own) {
-                const f32x4 ml = *reinterpret_cast<const f32x4*>(st + 8 * 256);
-                mp = ml[0];
-                lp = ml[1];
+                const float* st = state_of(gg);
 #pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8) og[g8] = *reinterpret_cast<const f32x4*>(st + g8 * 256);
+                for (int g8 = 0; g8 < 9; ++g8)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(og[g8]) : "v"(st + g8 * 256) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(og[0]), "+v"(og[1]), "+v"(og[2]), "+v"(og[3]), "+v"(og[4]), "+v"(og[5]), "+v"(og[6]), "+v"(og[7]), "+v"(og[8])
+                             :: "memory");
+                mp = __uint_as_float(og[8][0]);
+                lp = __uint_as_float(og[8][1]);
             } else {
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8)
-                    og[g8] = f32x4{acc_o[g8 >> 2][4 * (g8 & 3)], acc_o[g8 >> 2][4 * (g8 & 3) + 1], acc_o[g8 >> 2][4 * (g8 & 3) + 2],
-                                   acc_o[g8 >> 2][4 * (g8 & 3) + 3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) og[g8][r] = __float_as_uint(acc_o[g8 >> 2][4 * (g8 & 3) + r]);
             }
-            const float wgt = fast_exp2(mp - m_tot);           // an empty range (m = -inf) gets weight 0
-            l_tot += lp * wgt;
+            const float m_new = fmaxf(m_tot, mp);
+            const float w_old = fast_exp2(m_tot - m_new), w_seg = fast_exp2(mp - m_new);   // (first segment: w_old = exp2(-inf) = 0)
+            m_tot = m_new;
+            l_tot = l_tot * w_old + lp * w_seg;
 #pragma unroll
             for (int g8 = 0; g8 < 8; ++g8)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o_tot[g8 >> 2][4 * (g8 & 3) + r] += og[g8][r] * wgt;
+                for (int r = 0; r < 4; ++r)
+                    o_tot[g8 >> 2][4 * (g8 & 3) + r] = o_tot[g8 >> 2][4 * (g8 & 3) + r] * w_old + __uint_as_float(og[g8][r]) * w_seg;
         }
         l_run = l_tot;
         acc_o[0] = o_tot[0];
