@@ -2,8 +2,8 @@
 # One gpurun call that refreshes everything under profiles/ for a round (run from the repo root on the GPU box):
 #   bench lines (bf16 with CPU baseline + fp32 secondary), the other BASELINE.json configurations, rocprofv3 kernel trace +
 #   stats, three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES), micro-benchmarks.
-# usage: tools/measure_round.sh r02 <git commit>
-R="${1:-r02}"; COMMIT="${2:-unknown}"; O=gpurun_out/$R; mkdir -p $O
+# usage: tools/measure_round.sh r03 <git commit>
+R="${1:-r03}"; COMMIT="${2:-unknown}"; O=gpurun_out/$R; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
 make -C tools > /dev/null 2>&1
 python bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err || exit 1
@@ -26,6 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 8 pairs per update: the 256-row GEMM tiles at 3152 rows and the batched short-sequence attention
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_p8 -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --pairs 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/rocprof_trace_p8.err ) || exit 1
+python tools/vendor_compare.py > $O/vendor.txt 2> $O/vendor.err
 tools/launch_floor > $O/launch_floor.txt 2>&1
 tools/valu_rate > $O/valu_rate.txt 2>&1
 tools/op_chain > $O/op_chain_bf16.txt 2>&1

@@ -6,8 +6,8 @@ same random bf16 data as ``tools/big_ops``, next to this library's own kernels c
 
 Each line: shape | vendor us / TFLOP/s | ours us / TFLOP/s | ours / vendor.  The vendor GEMM computes A W^T + bias (no GELU,
 bf16 out): for the fc1 layers ours also applies GELU in its epilogue, i.e. does strictly more in the time shown.  Timing:
-HIP events around `reps` back-to-back launches on one stream, 4 rotating weight sets (so that W is not L2-resident from the
-previous launch, as in the forward), best of 3 rounds.
+`reps` back-to-back launches captured into one hipGraph and replayed (neither side pays host launch cost), 4 rotating
+weight sets (so that W is not L2-resident from the previous launch, as in the forward), best of 5 replays.
 """
 import ctypes as C
 import os
@@ -24,15 +24,35 @@ from vitvs_amd import _lib  # noqa: E402
 
 
 def timed(fn, reps):
-    for _ in range(5):
-        fn()
+    """us per call: `reps` calls captured into one hipGraph and replayed (no host launch cost on either side: torch's
+    Python dispatch is ~15 us per call, more than most of these kernels take), best of 5 replays; eager timing if the
+    capture fails."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):          # warm up ON the capture stream (the operator hook's workspace is per stream)
+        for _ in range(5):
+            fn()
+    torch.cuda.synchronize()
+    graph = None
+    try:
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(reps):
+                    fn()
+        graph = g
+    except Exception as exc:  # noqa: BLE001
+        print(f"# graph capture failed ({type(exc).__name__}: {exc}); eager timing", file=sys.stderr)
     torch.cuda.synchronize()
     best = 1e30
-    for _ in range(3):
+    for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            fn()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(reps):
+                fn()
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
@@ -47,7 +67,7 @@ def main():
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)   # noqa: E731
     p = lambda t: C.c_void_p(t.data_ptr())                             # noqa: E731
     g = torch.Generator(device="cpu").manual_seed(1)
-    print(f"# {torch.cuda.get_device_name(0)}, torch {torch.__version__}, bf16, random operands (uniform), {reps} launches x best of 3")
+    print(f"# {torch.cuda.get_device_name(0)}, torch {torch.__version__}, bf16, random operands (uniform), {reps} launches per graph replay, best of 5")
     print(f"{'GEMM  M x N x K':34s} | {'vendor (torch F.linear)':>24s} | {'ours (C ABI, auto tile)':>24s} | ours/vendor time")
     shapes = [("ViT-B/8 448  qkv", 6274, 2304, 768, 0, 0), ("ViT-B/8 448  fc1 (+GELU ours)", 6274, 3072, 768, 1, 0),
               ("ViT-B/8 448  fc2", 6274, 768, 3072, 0, -1), ("ViT-B/8 448  proj", 6274, 768, 768, 0, -1),

@@ -255,8 +255,10 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     const vitvs_config& c = h->cfg;
     const int D = c.dim;
     int rc = 0;
+#ifndef VITVS_PROBE_SKIP_PATCHIFY   // probe builds (tools/measure_round.sh): what removing this launch could save at most
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCHIFY, st);
         rc = launch_patchify(h->prec, cx[k].pa, cx[k].Ape, cx[k].x, st); }
+#endif
     // Patch embedding as a split-K GEMM (more workgroups than its 84 output tiles), finished together with
     // cls / pos_embed and block 0's norm1 by one residual_ln-style launch.
     // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
@@ -371,8 +373,10 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     a.v_c = v_c; a.status = status; a.nn1 = h->nn1; a.nn2 = h->nn2; a.sim1 = h->sim1; a.info = h->info;
     a.sel_out = h->sel_out; a.s_uv = h->s_uv; a.feat = h->feat; a.L_ws = h->Lws; a.max_rows = c.max_rows;
     h->last_pairs = n_pairs; h->last_T = T;
-    int rc;
+    int rc = 0;
+#ifndef VITVS_PROBE_SKIP_SERVO      // probe builds: the update without its last launch (upper bound of a Gram + servo fusion)
     { Span sp(h, KC_SERVO, st); rc = launch_servo(a, st); }
+#endif
     if (rc) return set_err(h, rc, "servo launch failed (LDS budget or bad arguments)");
     return 0;
 }
