@@ -353,9 +353,48 @@ def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=12.0):
             oracle_update(cfg, sd, des, cur, depth, params, order, exact)
             times.append(time.perf_counter() - t0)
         return times
-    legs = {}
-    for n_thr in sorted({min(16, usable), usable, host}):
-        legs[n_thr] = timed(n_thr, budget_s if n_thr == min(16, usable) else 4.0, 20)
+    def cpu_quota():
+        """CPUs the cgroup lets this process use at once (a GPU box hands out one GPU's share of the host whatever the
+        affinity mask says); None when unlimited or unknown."""
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                with open(path) as fh:
+                    parts = fh.read().split()
+                if path.endswith("cpu.max"):
+                    return None if parts[0] == "max" else max(1, int(int(parts[0]) / int(parts[1])))
+                q = int(parts[0])
+                if q <= 0:
+                    return None
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    return max(1, int(q / int(fh.read().split()[0])))
+            except (OSError, ValueError, IndexError):
+                continue
+        return None
+    quota = cpu_quota()
+    legs, skipped = {}, {}
+    base = min(16, usable)
+    legs[base] = timed(base, budget_s, 20)
+    base_med = float(np.median(legs[base]))
+    for n_thr in sorted({usable, host} - {base}):
+        if quota is not None and n_thr > 2 * quota:
+            skipped[str(n_thr)] = f"not timed: the cgroup allows {quota} CPUs, {n_thr} threads would only time-slice them"
+            continue
+        # a cheap guard first: an oversubscribed pool (more threads than CPUs really granted) makes one update take tens of
+        # seconds; a few small matmuls show it in well under a second
+        def probe(threads):
+            torch.set_num_threads(threads)
+            a_ = torch.ones((768, 768))
+            torch.mm(a_, a_)
+            t0 = time.perf_counter()
+            for _ in range(8):
+                torch.mm(a_, a_)
+            return time.perf_counter() - t0
+        p_base, p_thr = probe(base), probe(n_thr)
+        if p_thr > 3.0 * p_base:
+            skipped[str(n_thr)] = (f"not timed: 8 matmuls of 768^3 take {p_thr * 1e3:.0f} ms on {n_thr} threads against "
+                                   f"{p_base * 1e3:.0f} ms on {base}: the pool is oversubscribed")
+            continue
+        legs[n_thr] = timed(n_thr, 4.0, 20)
     best_thr = min(legs, key=lambda k_: float(np.median(legs[k_])))
     many = legs[best_thr]
     loop = timed(best_thr, 4.0, 10, exact=True)
@@ -366,6 +405,7 @@ def cpu_baseline(cfg, sd, des, cur, depth, params, budget_s=12.0):
     return dict(value=round(1.0 / med, 3), unit="updates/s", cores=best_thr, kind="port",
                 p90_ms=round(p90 * 1e3, 2), median_ms=round(med * 1e3, 2), threads_1_value=round(1.0 / med1, 3),
                 threads_1_median_ms=round(med1 * 1e3, 2), cpu_model=cpu_model(), host_cpus=host, usable_cpus=usable,
+                cgroup_cpus=quota, thread_counts_not_timed=skipped,
                 by_threads={str(k_): dict(value=round(1.0 / float(np.median(v_)), 3), median_ms=round(float(np.median(v_)) * 1e3, 2),
                                           updates=len(v_)) for k_, v_ in legs.items()},
                 reference_loop=dict(value=round(1.0 / medl, 3), median_ms=round(medl * 1e3, 2), threads=best_thr, updates=len(loop),
