@@ -56,7 +56,7 @@ def _setup(precision, selection):
 
 
 def _oracle_tokens(cfg, sd, rgb_cam):
-    small = np.asarray(Image.fromarray(rgb_cam).resize((cfg.img_size, cfg.img_size)))     # vitvs_v2.py:474-475
+    small = np.array(Image.fromarray(rgb_cam).resize((cfg.img_size, cfg.img_size)))       # vitvs_v2.py:474-475
     return vit_ref.block_tokens(sd, small[None], patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer,
                                 mean=cfg.mean, std=cfg.std)[0, 1:]
 
