@@ -104,6 +104,12 @@ def load():
         raise VitvsLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C vit-vs_amd/csrc`).  There is no CPU fallback for the hot path.")
+    # torch first: its wheel bundles its own libamdhip64, and a process must end up with ONE HIP runtime.  Loaded after
+    # torch, this library's DT_NEEDED libamdhip64 resolves to the copy torch already mapped; loaded before it, the system
+    # copy is mapped, torch then brings its own, and the two runtimes do not see each other's devices and streams
+    # (symptom: vitvs_create "no HIP device available" in a process that called build() — which loads the library —
+    # before anything imported torch).  Python callers of this binding always use torch for device memory and streams.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in PROTOTYPES.items():
         try:
