@@ -293,6 +293,15 @@ def test_split_attention_on_two_streams_at_once(lib):
     torch.cuda.synchronize()
     for i in range(6):
         assert torch.equal(outs_a[i], alone[0]) and torch.equal(outs_b[i], alone[1])
+    # ONE stream, alternating inputs back to back: every launch reuses the same workspace slots for different states; a merge
+    # that read a range's state from an older launch (a stale cache line behind the fence-free hand-off) would mix A and B
+    seq = [qa, qb, qb, qa, qb, qa, qa, qb]
+    outs = [torch.empty_like(alone[0]) for _ in seq]
+    for q, o in zip(seq, outs):
+        assert lib.vitvs_op_attention(_lib.BF16, _p(q), _p(o), n_img, N, H, _stream()) == 0
+    torch.cuda.synchronize()
+    for q, o in zip(seq, outs):
+        assert torch.equal(o, alone[0] if q is qa else alone[1])
 
 
 @pytest.mark.parametrize("slope", [0.004, 0.02, 0.05, 0.2])

@@ -1011,6 +1011,29 @@ def test_update_is_bit_reproducible_run_to_run(precision):
             assert np.array_equal(a, b)
 
 
+def test_many_token_updates_alternating_inputs_are_bit_reproducible():
+    """DINOv2 ViT-L/14 518² in fp16 (1370 tokens: the attention ranges of a query block are merged inside the launch through
+    a workspace that every launch reuses, the Gram runs from the f16 split): two different frame pairs alternated back to back
+    on one handle give, each time, exactly what they give first — indices, similarities and v_c bit for bit."""
+    cfg = config.baseline_config("vitl14_518")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _engine(cfg, params, precision="fp16", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    pairs = [synth.frame_pair(cfg.img_size, 20250705), synth.frame_pair(cfg.img_size, 20250911)]
+    order = torch.randperm(cfg.tokens, generator=torch.Generator().manual_seed(3)).to(torch.int32)[None]
+    first = {}
+    for which in (0, 1, 1, 0, 1, 0, 0, 1):
+        des, cur = pairs[which]
+        v, st = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order)
+        det = eng.last_details(1)
+        got = (v.cpu().numpy().copy(), det["nn_1"].copy(), det["nn_2"].copy(), det["sim_1"].copy())
+        if which not in first:
+            first[which] = got
+        else:
+            for a, b in zip(first[which], got):
+                assert np.array_equal(a, b)
+    assert not np.array_equal(first[0][1], first[1][1])
+
+
 def test_swapping_the_frames_swaps_the_nearest_neighbour_tables():
     """S(cur, des) = S(des, cur)^T: row arg-maxes of one are column arg-maxes of the other (full-size ViT-B/16 pair,
     fp32; the fixture's margins rule out ties)."""
