@@ -96,8 +96,9 @@ def test_linear_tile_plan_of_the_library():
     assert plan(b, 394, 2304, 768) == (64, 64, 2)
     assert plan(b, 394, 768, 3072, 3) == (64, 64, 2)
     assert plan(b, 788, 2304, 768) == (64, 128, 2)           # two pairs: still one round of 64-row tiles
-    assert plan(b, 788, 3072, 768) == (192, 128, 0)          # 120 tiles of 192 x 128 against 96 of 256 x 128
-    assert plan(b, 985, 2304, 768) == (192, 128, 0)          # rotation search (5 images): a second round of 64-row tiles loses
+    assert plan(b, 788, 3072, 768) == (64, 128, 1)           # 312 workgroups on a 2-stage ring (3 per CU) against 120 tiles of 192 x 128
+    assert plan(b, 985, 2304, 768) == (64, 128, 1)           # rotation search (5 images): 288 workgroups, still one round
+    assert plan(b, 1182, 2304, 768) == (192, 128, 0)         # 342 workgroups: no gain in the forward, the persistent tiles keep it
     assert plan(b, 2364, 3072, 768) == (256, 128, 0)         # 120 tiles of 256 x 256 would leave half the CUs idle
     assert plan(b, 3152, 3072, 768) == (256, 192, 0)         # 8 pairs: 208 tiles of 256 x 192 in one round beat 156 of 256 x 256
     assert plan(b, 3152, 2304, 768) == (256, 128, 0)

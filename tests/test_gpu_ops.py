@@ -67,7 +67,11 @@ def test_linear(lib, name, prec, dtype, tol, M, N, K, gelu):
 
 
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
-@pytest.mark.parametrize("M,N,K,use_ls", [(394, 768, 768, False), (394, 768, 3072, True), (130, 384, 1536, True)])
+@pytest.mark.parametrize("M,N,K,use_ls", [(394, 768, 768, False), (394, 768, 3072, True), (130, 384, 1536, True),
+                                          # 300 / 600 workgroups of 64 x 64: the 3- and the 2-stage ring (ring_stages, gemm.hip);
+                                          # K = 192 / 64: fewer k-tiles than the ring has stages
+                                          (1576, 768, 768, True), (3152, 768, 768, False), (1576, 768, 192, False),
+                                          (3100, 768, 64, True)])
 def test_linear_residual(lib, name, prec, dtype, tol, M, N, K, use_ls):
     g = torch.Generator().manual_seed(M + N + K)
     A = _mk((M, K), g).to(dtype)

@@ -73,14 +73,17 @@ int main(int argc, char** argv) {
         {"1500x2304 K=3072 ", 1500, 2304, 3072, 0, 0},
     };
     // "mid": 2..6 frame pairs (788..2364 rows) through the four layer shapes of ViT-B/16: where does each tile family win?
-    const bool mid_mode = argc > 1 && !strcmp(argv[1], "mid");
+    // "midl": the same for ViT-L/14 at 224² (257 tokens per frame)
+    const bool midl = argc > 1 && !strcmp(argv[1], "midl");
+    const bool mid_mode = midl || (argc > 1 && !strcmp(argv[1], "mid"));
     std::vector<Shape> mid_shapes;
     static char mid_names[64][24];
     if (mid_mode) {
         int q = 0;
-        for (int rows : {788, 985, 1182, 1576, 1970, 2364})
+        for (int rows : midl ? std::vector<int>{514, 1028, 1542, 2056} : std::vector<int>{788, 985, 1182, 1576, 1970, 2364})
             for (int layer = 0; layer < 4; ++layer) {
-                const int N = layer == 0 ? 2304 : layer == 1 ? 3072 : 768, K = layer == 2 ? 3072 : 768;
+                const int D = midl ? 1024 : 768;
+                const int N = layer == 0 ? 3 * D : layer == 1 ? 4 * D : D, K = layer == 2 ? 4 * D : D;
                 snprintf(mid_names[q], sizeof(mid_names[q]), "%4d rows %s", rows, layer == 0 ? "qkv " : layer == 1 ? "fc1 " : layer == 2 ? "fc2 " : "proj");
                 mid_shapes.push_back(Shape{mid_names[q], rows, N, K, layer == 1, layer >= 2 ? -1 : 0});
                 ++q;
@@ -96,7 +99,11 @@ int main(int argc, char** argv) {
         {"1576 proj 1 slice ", 1576, 768, 768, 0, 1},  {"1576 proj 2 slices", 1576, 768, 768, 0, 2},  {"1576 proj 3 slices", 1576, 768, 768, 0, 3},
         {"1576 fc2  3 slices", 1576, 768, 3072, 0, 3}, {"1576 fc2  4 slices", 1576, 768, 3072, 0, 4}, {"1576 fc2  6 slices", 1576, 768, 3072, 0, 6},
     };
-    const int nsets = 4;
+    // weight sets a layer rotates through.  4 (the default, as in the profiles of rounds 2-3) keeps them in the 256 MB
+    // infinity cache; VITVS_WEIGHT_MB=512 rotates through that many MB per layer shape, so that every launch fetches its
+    // weights from HBM as the forward does (12 layers x 14 MB + activations per update do not stay cached)
+    const long weight_mb = getenv("VITVS_WEIGHT_MB") ? atol(getenv("VITVS_WEIGHT_MB")) : 0;
+    const int max_sets = 512;
     printf("%-20s %6s %6s %6s | %-28s\n", "layer (bf16, random)", "M", "N", "K", "us / TFLOP/s per tile family: auto, 64-row tiles, 256x256, 256x128, 128x128, 256x192, 192x128, 192x256");
     // "occ": attention only, on a probe build of the library, with the workgroups per CU limited through their LDS size
     const bool occ = argc > 1 && !strcmp(argv[1], "occ");
@@ -109,7 +116,8 @@ int main(int argc, char** argv) {
     else todo.assign(std::begin(shapes), std::end(shapes));
     for (const Shape& s : todo) {
         void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
-        void* Wt[nsets];
+        const int nsets = weight_mb > 0 ? (int)std::min<long>(max_sets, std::max<long>(4, weight_mb * 1000000 / ((long)s.N * s.K * 2))) : 4;
+        void* Wt[max_sets];
         for (int i = 0; i < nsets; ++i) Wt[i] = rand_bf16((size_t)s.N * s.K, 0.05f, 2 + i);
         void* out;
         const int sl = s.slices < 0 ? vitvs_op_splitk_slices(VITVS_BF16, s.M, s.N, s.K) : s.slices;   // -1: the library's choice

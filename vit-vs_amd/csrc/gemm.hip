@@ -122,7 +122,7 @@ struct EpiPartial {
 __device__ unsigned long long* g_gemm_probe;
 #endif
 
-template <typename T, int BM, int BN, int KG, class Epi>
+template <typename T, int BM, int BN, int KG, class Epi, int NS = 0>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
                                                           int ks_i0) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #else
     unsigned long long* const ts = nullptr;
 #endif
-    using Tile = GemmTile<BM, BN, KG>;
+    using Tile = GemmTile<BM, BN, KG, NS>;
     Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned pk = (unsigned)ks_i0;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     float4 col[Tile::NT];
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) col[ni] = epi.column_terms(min(n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4), N - 4));
-    gemm_mainloop<T, BM, BN, KG>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc, ts);
+    gemm_mainloop<T, BM, BN, KG, NS>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc, ts);
 #ifdef VITVS_PROBE
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
     ts[4] = __builtin_readcyclecounter();
@@ -229,17 +229,36 @@ struct EpiArgs {   // host image of the flat epilogue arguments
     int i0;
 };
 
-template <typename T, int BN, int KG, class Epi, int BM = 64>
+template <typename T, int BN, int KG, class Epi, int BM = 64, int NS = 0>
 static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs& e, hipStream_t stream, int splits) {
-    using Tile = GemmTile<BM, BN, KG>;
+    using Tile = GemmTile<BM, BN, KG, NS>;
     static std::atomic<unsigned long long> raised{0};   // > 64 KiB of dynamic LDS needs the opt-in attribute, per device
-    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi>), Tile::LDS_BYTES, raised)) return -1;
+    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi, NS>), Tile::LDS_BYTES, raised)) return -1;
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
     const int kslice = K / splits;
     if (kslice % 32 != 0 || kslice / 32 > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff) return -2;
-    launch(linear_kernel<T, BM, BN, KG, Epi>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1, M,
-           N, K, (int)(((unsigned)(kslice / 32) << 24) | (unsigned)e.i0));
+    launch(linear_kernel<T, BM, BN, KG, Epi, NS>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1,
+           M, N, K, (int)(((unsigned)(kslice / 32) << 24) | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Ring depth of a one-k-group 64-row launch.  Up to one workgroup per CU the deep ring (4 stages) hides the operand latency
+// of the only workgroup there is.  Beyond that the LDS footprint sets how many workgroups a CU holds at once, and the other
+// resident workgroups hide the latency instead (bf16, us with 4 / 3 / 2 stages; weights rotating through 19 MB | 600 MB):
+//   64 x 64  (64 / 48 / 32 KB: 2 / 3 / 5 per CU)  1576 x 768 x 768, 300 workgroups:  6.1 /  6.0 /  7.6 |  7.1 /  7.3 / 10.7
+//                                                 3152 x 768 x 768, 600:            12.0 / 11.5 / 10.3 | 12.1 / 11.6 / 12.0
+//                                                 2740 x 1024 x 1024, 688:          14.8 / 13.1 / 12.4 | 15.4 / 14.7 / 15.4
+//   64 x 128 (96 / 72 / 48 KB: 1 / 2 / 3 per CU)   788 x 3072 x 768, 312:           20.3 / 12.2 / 11.4 | 20.7 / 13.0 / 15.6
+//                                                  985 x 2304 x 768, 288:           18.4 / 11.1 / 11.3 | 18.8 / 11.9 / 13.7
+// In the forward (kernel trace, same box): 8-pair proj 11.40 / 11.47 / 11.31 us, 2-pair fc1 19.8 / 13.5 / 12.2 us; end to end
+// against 4 stages everywhere: 8 pairs +0.9 ... +1.3 % with 3 or 2 stages, 2 pairs +1.6 % (profiles/r03_notes.md).
+static int ring_stages(int bn, long wgs) {
+#ifdef VITVS_RING_FIXED                       // experiments (tools/): one depth for every one-k-group 64-row launch (0 = the default, 4)
+    return VITVS_RING_FIXED;
+#endif
+    if (wgs <= 256) return 0;                 // the tile's default
+    if (bn == 128) return 2;
+    return wgs <= 512 ? 3 : 2;
 }
 
 // Many-row problems (many frame pairs, 448² / 518² inputs): 128x128 tiles halve the LDS and L2 bytes per MFMA.
@@ -250,21 +269,32 @@ static bool big_problem(int M, int N, int splits) {
 }
 
 template <typename T, class Epi>
+static int launch_64wide(const T* A, const T* W, int M, int N, int K, const EpiArgs& epi, hipStream_t stream, int splits, int kg,
+                         int ns) {
+    if (kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+    if (ns == 3) return launch_one<T, 64, 1, Epi, 64, 3>(A, W, M, N, K, epi, stream, splits);
+    if (ns == 2) return launch_one<T, 64, 1, Epi, 64, 2>(A, W, M, N, K, epi, stream, splits);
+    return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);
+}
+
+template <typename T, class Epi>
 static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiArgs& epi, hipStream_t stream,
                         int splits = 1, bool fixed64 = false) {
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
+    const int ns = pl.kg == 1 ? ring_stages(pl.bn, (long)((M + 63) / 64) * (N / pl.bn) * splits) : 0;
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
+        if (ns == 2) return launch_one<T, 128, 1, Epi, 64, 2>(A, W, M, N, K, epi, stream, splits);
+        if (ns == 3) return launch_one<T, 128, 1, Epi, 64, 3>(A, W, M, N, K, epi, stream, splits);
         return launch_one<T, 128, 1, Epi>(A, W, M, N, K, epi, stream, splits);
     }
     if (pl.bn == 96) {
         if (pl.kg == 2) return launch_one<T, 96, 2, Epi>(A, W, M, N, K, epi, stream, splits);
         return launch_one<T, 96, 1, Epi>(A, W, M, N, K, epi, stream, splits);
     }
-    if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
-    return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);
+    return launch_64wide<T, Epi>(A, W, M, N, K, epi, stream, splits, pl.kg, ns);
 }
 
 // narrow layers / patch embed: 64-wide tiles only (keeps the number of instantiations down)
@@ -274,8 +304,8 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, true);
-    if (pl.kg == 2) return launch_one<T, 64, 2, Epi>(A, W, M, N, K, epi, stream, splits);
-    return launch_one<T, 64, 1, Epi>(A, W, M, N, K, epi, stream, splits);
+    const int ns = pl.kg == 1 ? ring_stages(64, (long)((M + 63) / 64) * (N / 64) * splits) : 0;
+    return launch_64wide<T, Epi>(A, W, M, N, K, epi, stream, splits, pl.kg, ns);
 }
 
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

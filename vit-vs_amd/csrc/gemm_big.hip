@@ -429,6 +429,11 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
         if (partial && c != 64) continue;                         // the partial-sum kernels of gemm.hip are 64 wide
         if (N % c == 0 && mt * (N / c) * splits <= 256) return 0;
     }
+    // A little over one workgroup per CU, the 64 x 128 tiles of gemm.hip on their 2-stage ring (48 KB: three resident per CU, so
+    // still one round) are ahead of every tile of this file: 788 x 3072 x 768 (312 workgroups) 11.4-12.5 us against 13.3 on
+    // 192 x 128 tiles, 985 x 2304 (288) 11.3 / 11.8; end to end +1.6 % at 2 frame pairs.  From ~340 workgroups on the forward
+    // does not gain (3 pairs, qkv 1182 x 2304: -0.4 % end to end although 11.7 / 11.8 us alone), so the rule stops at 320.
+    if (!partial && splits == 1 && N % 128 == 0 && mt * (N / 128) <= 320) return 0;
     const long ny = (M + 255) / 256;
     if (N % 128 != 0 || N / 128 > 255) return 0;
     const long t128 = ny * (N / 128) * splits;

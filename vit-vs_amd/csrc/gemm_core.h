@@ -44,7 +44,7 @@ __device__ __forceinline__ f32x4 mma_chunk<bf16>(f32x4 acc, u32x4 a, u32x4 b) {
                                                    0, 0);
 }
 
-template <int BM, int BN, int KG = 1>
+template <int BM, int BN, int KG = 1, int NS = 0>
 struct GemmTile {
     static constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     static constexpr int MT = WM / 16, NT = WN / 16;    // 16x16 MFMA tiles per wave
@@ -54,7 +54,9 @@ struct GemmTile {
     // with two k-groups (a 4-stage ring there measured slower).  The 128-row tiles serve many-row problems that run
     // several waves of workgroups: there occupancy wins — 2 stages = 64 KB (128x128) or 48 KB (128x64), i.e. 2-3
     // workgroups per CU, measured -24 ... -27 % on the 6274-row fc1 / qkv GEMMs against 4 stages (1 workgroup per CU).
-    static constexpr int NST = (BM >= 128) ? 2 : ((KG == 1) ? 4 : 3);
+    // NS > 0 overrides the depth: the launchers of gemm.hip pick a shallower ring for 64-row launches of more than one
+    // workgroup per CU, where the LDS footprint decides how many are resident (ring_stages() there has the measurements).
+    static constexpr int NST = NS ? NS : ((BM >= 128) ? 2 : ((KG == 1) ? 4 : 3));
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
     static constexpr int RING_BYTES = KG * GROUP_BYTES;
@@ -86,14 +88,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // caller must mask).  k range [k_begin, k_end) must be a multiple of KG k-tiles.  On return the
 // accumulators hold the full sums for the column tiles the wave's k-group owns (tile_owner); with
 // KG = 1 that is every tile.
-template <typename T, int BM, int BN, int KG>
+template <typename T, int BM, int BN, int KG, int NS = 0>
 __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* __restrict__ W, int lda, int ldw,
                                               int m_rows, int n_rows, int m0, int n0, int k_begin, int k_end,
                                               unsigned char* smem,
                                               f32x4 (&acc)[GemmTile<BM, BN, KG>::NT][GemmTile<BM, BN, KG>::MT],
                                               unsigned long long* ts = nullptr) {
     // ts: cycle-counter stamps of the phases (probe builds, tools/gemm_probe.cpp); null in production (folded away)
-    using Tile = GemmTile<BM, BN, KG>;
+    using Tile = GemmTile<BM, BN, KG, NS>;
     constexpr int EPC = Elem<T>::PER_CHUNK;
     constexpr int BK = 8 * EPC;
     constexpr int L = Tile::L, NST = Tile::NST;
