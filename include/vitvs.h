@@ -20,7 +20,8 @@
  *     handles of several GPUs may be driven from one thread.
  *   - images are RGB uint8, HWC, already resized to img_size x img_size (reference:
  *     vitvs_v2.py:474-475 PIL resize happens before the path; dinov2_extractor.py:177-191);
- *     vitvs_resize_frames_dev does that resize on the device, bit-identically to PIL.
+ *     vitvs_resize_frames_dev does that resize on the device, bit-identically to PIL, and after
+ *     vitvs_set_frame_size the path takes camera-resolution frames and resizes while it builds its patch rows.
  *   - depth is the sensor's uint16 millimetre image, 0 = invalid (reference:
  *     realsense_gazebo_plugin/src/RealSensePlugin.cpp:250-262, consumed at vitvs_v2.py:566-586).
  */
@@ -141,6 +142,14 @@ VITVS_API int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_d
  * uploads them (one synchronisation); later calls only enqueue one launch. */
 VITVS_API int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t in_h, int32_t in_w,
                             uint8_t* out, void* stream);
+/* The same resize INSIDE the path ("fused into the patch-embed load"): declares that every frame argument
+ * handed to this handle from now on (I_cur, I_des, frames of every entry point above and below) is a camera frame
+ * uint8 [in_h][in_w][3].  The launch that builds the patch rows then computes each pixel of the img_size x img_size image
+ * PIL would have produced (same integer arithmetic as vitvs_resize_frames_dev, bit-identical) from the camera frame: no
+ * resized image in memory, no extra launch.  (0, 0) or (img_size, img_size) restores frames at img_size x img_size.
+ * Synchronises the device and rebuilds the tables when the geometry changes; cheap when it does not.  -3: the frame is too
+ * large for the kernel's 64 KB of intermediate rows (several thousand pixels high) — use vitvs_resize_frames_dev. */
+VITVS_API int vitvs_set_frame_size(vitvs_handle* h, int32_t in_h, int32_t in_w);
 
 /* --- the seams inside it (same split as the reference's callables) ------------------------------
  * ViTExtractor.extract_descriptors(batch, layer, 'token', bin) (dinov2_extractor.py:313-337):

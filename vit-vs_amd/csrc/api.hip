@@ -68,9 +68,10 @@ struct vitvs_handle {
     std::map<std::string, bool> have;
     int desc_keys = -1;   // >= 0 while a velocity update runs: the forward's last launch emits the descriptors and clears this many keys
     bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
-    // Pillow-exact resize tables of the last camera frame size (vitvs_resize_frames_dev)
-    int rs_h = 0, rs_w = 0, rs_ksx = 0, rs_ksy = 0;
-    int *rs_xb = nullptr, *rs_xk = nullptr, *rs_yb = nullptr, *rs_yk = nullptr;
+    // Pillow-exact resize tables: `rs` of the last camera frame size seen by vitvs_resize_frames_dev, `fr` of the frame
+    // geometry declared with vitvs_set_frame_size (fr.in_h == 0: frames arrive at img_size x img_size)
+    ResizeArgs rs{}, fr{};
+    size_t staged_frame_bytes = 0;   // capacity per frame of st_cur / st_des
     // weights
     std::vector<Block> blk;
     void* pe_w = nullptr;
@@ -234,6 +235,11 @@ struct Span {
     }
 };
 
+// Bytes of one frame as the caller hands it over: img_size x img_size x 3, or the declared camera geometry.
+static size_t frame_bytes(const vitvs_handle* h) {
+    return h->fr.in_h ? (size_t)h->fr.in_h * h->fr.in_w * 3 : (size_t)h->cfg.img_size * h->cfg.img_size * 3;
+}
+
 // One launch chain's view of the workspaces (a contiguous range of images).
 // Plain descriptors of the default forward are produced by the forward's own last launch.
 static bool desc_in_forward(const vitvs_handle* h) { return !h->cfg.binned && h->Dp == h->cfg.dim; }
@@ -244,6 +250,7 @@ struct ChainCtx {
     unsigned char *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr, *Ape = nullptr;
     float* part = nullptr;
     PatchifyArgs pa;
+    const ResizeArgs* rs = nullptr;   // camera-resolution frames (vitvs_set_frame_size): resize inside the patch-row build
     bool want_desc = false;   // the last residual_ln also writes the plain descriptors (launch_residual_ln)
     DescOut desc;
 };
@@ -257,7 +264,7 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     int rc = 0;
 #ifndef VITVS_PROBE_SKIP_PATCHIFY   // probe builds (tools/measure_round.sh): what removing this launch could save at most
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCHIFY, st);
-        rc = launch_patchify(h->prec, cx[k].pa, cx[k].Ape, cx[k].x, st); }
+        rc = launch_patchify(h->prec, cx[k].pa, cx[k].rs, cx[k].Ape, cx[k].x, st); }
 #endif
     // Patch embedding as a split-K GEMM (more workgroups than its 84 output tiles), finished together with
     // cls / pos_embed and block 0's norm1 by one residual_ln-style launch.
@@ -300,9 +307,10 @@ ChainCtx fill_ctx(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     const vitvs_config& c = h->cfg;
     const int D = c.dim;
     const size_t es = elem_size(h->prec);
-    const size_t img_bytes = (size_t)c.img_size * c.img_size * 3;
+    const size_t img_bytes = frame_bytes(h);
     const size_t row0 = (size_t)i0 * h->N;
     ChainCtx cx;
+    cx.rs = h->fr.in_h ? &h->fr : nullptr;
     cx.cnt = cnt; cx.M = cnt * h->N; cx.part = part;
     cx.x = h->x + row0 * D;
     cx.xn = (unsigned char*)h->xn + row0 * D * es;
@@ -464,6 +472,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     if (!rc) rc = dev_alloc(h, &h->feat, P * R * 4);
     if (!rc) rc = dev_alloc(h, &h->Lws, P * 7 * 2 * R);
     const size_t img_bytes = (size_t)cfg->img_size * cfg->img_size * 3;
+    h->staged_frame_bytes = img_bytes;
     if (!rc) rc = dev_alloc(h, &h->st_cur, P * img_bytes);
     if (!rc) rc = dev_alloc(h, &h->st_des, P * img_bytes);
     if (!rc) rc = dev_alloc(h, &h->st_depth, P * (size_t)cfg->u_max * cfg->v_max);
@@ -610,31 +619,77 @@ static int upload_table(vitvs_handle* h, const std::vector<int>& v, int** dev) {
     return 0;
 }
 
+// Pillow's tables for (in_h, in_w) -> img_size in `t` (a new resolution replaces the previous tables; synchronises once).
+static int resize_tables(vitvs_handle* h, ResizeArgs& t, int in_h, int in_w) {
+    if (in_h == t.in_h && in_w == t.in_w) return 0;
+    for (const int** d : {&t.xb, &t.xk, &t.yb, &t.yk}) {
+        if (*d) {
+            VITVS_HIP_CHECK(hipDeviceSynchronize());   // a launch on ANY stream may still read them
+            h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*d), h->allocs.end());
+            (void)hipFree((void*)*d);
+            *d = nullptr;
+        }
+    }
+    t = ResizeArgs{};
+    if (in_h == 0 && in_w == 0) return 0;
+    const int S = h->cfg.img_size, patch = h->cfg.patch;
+    std::vector<int> xb, xk, yb, yk;
+    const int ksx = resize_coefficients(in_w, S, xb, xk);
+    const int ksy = resize_coefficients(in_h, S, yb, yk);
+    // the patch-row build (patchify_resize_kernel) takes the camera rows of a patch from its first and last pixel row: both
+    // bounds of Pillow's windows grow with the output row (they do: the centre does), checked here rather than assumed
+    int rows = 0;
+    for (int y = 0; y + 1 < S; ++y)
+        if (yb[2 * y] > yb[2 * y + 2] || yb[2 * y] + yb[2 * y + 1] > yb[2 * y + 2] + yb[2 * y + 3]) return set_err(h, -5, "resize windows are not monotone");
+    for (int y = 0; y + patch <= S; ++y) rows = std::max(rows, yb[2 * (y + patch - 1)] + yb[2 * (y + patch - 1) + 1] - yb[2 * y]);
+    int *dxb = nullptr, *dxk = nullptr, *dyb = nullptr, *dyk = nullptr;
+    if (upload_table(h, xb, &dxb) || upload_table(h, xk, &dxk) || upload_table(h, yb, &dyb) || upload_table(h, yk, &dyk))
+        return set_err(h, -6, "resize table upload failed");
+    t.xb = dxb; t.xk = dxk; t.yb = dyb; t.yk = dyk;
+    t.in_h = in_h; t.in_w = in_w; t.ksx = ksx; t.ksy = ksy; t.rows = rows;
+    return 0;
+}
+
 int vitvs_resize_frames_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t in_h, int32_t in_w,
                             uint8_t* out, void* stream) {
     if (!h || !frames || !out) return set_err(h, -1, "null argument");
     if (n_frames <= 0 || in_h <= 0 || in_w <= 0) return set_err(h, -5, "bad frame geometry");
     DeviceScope dev(h);
-    if (in_h != h->rs_h || in_w != h->rs_w) {   // new camera resolution: build the coefficient tables (synchronises once)
-        for (int** t : {&h->rs_xb, &h->rs_xk, &h->rs_yb, &h->rs_yk}) {   // drop the previous resolution's tables
-            if (*t) {
-                VITVS_HIP_CHECK(hipDeviceSynchronize());   // a resize launched on ANY stream may still read them
-                h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*t), h->allocs.end());
-                (void)hipFree(*t);
-                *t = nullptr;
-            }
-        }
-        std::vector<int> xb, xk, yb, yk;
-        const int ksx = resize_coefficients(in_w, h->cfg.img_size, xb, xk);
-        const int ksy = resize_coefficients(in_h, h->cfg.img_size, yb, yk);
-        if (upload_table(h, xb, &h->rs_xb) || upload_table(h, xk, &h->rs_xk) || upload_table(h, yb, &h->rs_yb) ||
-            upload_table(h, yk, &h->rs_yk))
-            return set_err(h, -6, "resize table upload failed");
-        h->rs_h = in_h; h->rs_w = in_w; h->rs_ksx = ksx; h->rs_ksy = ksy;
-    }
-    const int rc = launch_resize_bicubic(frames, out, n_frames, in_h, in_w, h->cfg.img_size, h->rs_xb, h->rs_xk, h->rs_ksx,
-                                         h->rs_yb, h->rs_yk, h->rs_ksy, as_stream(stream));
+    if (int rc = resize_tables(h, h->rs, in_h, in_w)) return rc;
+    const int rc = launch_resize_bicubic(frames, out, n_frames, in_h, in_w, h->cfg.img_size, h->rs.xb, h->rs.xk, h->rs.ksx,
+                                         h->rs.yb, h->rs.yk, h->rs.ksy, as_stream(stream));
     if (rc) return set_err(h, rc, "resize launch failed");
+    return 0;
+}
+
+int vitvs_set_frame_size(vitvs_handle* h, int32_t in_h, int32_t in_w) {
+    if (!h) return set_err(h, -1, "null argument");
+    if (in_h < 0 || in_w < 0 || (in_h == 0) != (in_w == 0)) return set_err(h, -5, "bad frame geometry");
+    DeviceScope dev(h);
+    if (in_h == h->cfg.img_size && in_w == h->cfg.img_size) in_h = in_w = 0;   // nothing to resize: the plain patch-row build
+    if (in_h == h->fr.in_h && in_w == h->fr.in_w) return 0;
+    // captured updates hold the previous tables' addresses: they go (a cached goal's tokens do not depend on the geometry and stay)
+    VITVS_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+    if (int rc = resize_tables(h, h->fr, in_h, in_w)) return rc;
+    if (h->fr.in_h && (size_t)h->fr.rows * h->cfg.patch * 3 > 64 * 1024) {
+        (void)resize_tables(h, h->fr, 0, 0);
+        return set_err(h, -3, "camera frame too large for the fused resize (use vitvs_resize_frames_dev)");
+    }
+    if (frame_bytes(h) > h->staged_frame_bytes) {   // host-buffer entry points stage whole frames
+        const size_t P = (size_t)h->cfg.max_pairs;
+        for (uint8_t** b : {&h->st_cur, &h->st_des}) {
+            h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*b), h->allocs.end());
+            (void)hipFree(*b);
+            *b = nullptr;
+            if (dev_alloc(h, b, P * frame_bytes(h))) return set_err(h, -6, "frame staging allocation failed");
+        }
+        h->staged_frame_bytes = frame_bytes(h);
+    }
     return 0;
 }
 
@@ -773,7 +828,7 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
     const std::vector<uintptr_t> key = {(uintptr_t)u.n_pairs, (uintptr_t)u.I_cur, (uintptr_t)u.I_des, (uintptr_t)u.des_shared,
                                         (uintptr_t)u.Z_mm, (uintptr_t)u.K, (uintptr_t)u.select_mode, (uintptr_t)u.num_pairs,
                                         (uintptr_t)(u.selection != nullptr), (uintptr_t)(u.n_selected != nullptr),
-                                        (uintptr_t)u.v_c, (uintptr_t)u.status};
+                                        (uintptr_t)u.v_c, (uintptr_t)u.status, (uintptr_t)h->fr.in_h, (uintptr_t)h->fr.in_w};
     vitvs_handle::GraphEntry* ge = nullptr;
     for (auto& g : h->graphs)
         if (g.key == key) ge = &g;
@@ -828,7 +883,7 @@ int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des) {
     if (!h || !I_des) return set_err(h, -1, "null argument");
     if (n_goal <= 0 || n_goal > h->cfg.max_pairs) return set_err(h, -3, "n_goal exceeds max_pairs");
     DeviceScope dev(h);
-    const size_t img = (size_t)h->cfg.img_size * h->cfg.img_size * 3;
+    const size_t img = frame_bytes(h);
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, n_goal * img, hipMemcpyHostToDevice, nullptr));
     const int rc = vitvs_set_goal_dev(h, n_goal, h->st_des, nullptr);
     if (rc) return rc;
@@ -869,7 +924,7 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     const int np = call_num_pairs(h, num_pairs);
     if (np > c.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
     DeviceScope dev(h);
-    const size_t img = (size_t)c.img_size * c.img_size * 3;
+    const size_t img = frame_bytes(h);
     hipStream_t st = nullptr;
     VITVS_HIP_CHECK(hipMemcpyAsync(h->st_cur, I_cur, n_pairs * img, hipMemcpyHostToDevice, st));
     if (I_des) VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, (des_shared ? 1 : n_pairs) * img, hipMemcpyHostToDevice, st));

@@ -63,10 +63,80 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
     }
 }
 
-int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hipStream_t stream) {
+// Camera-resolution frames: the reference's PIL resize in front of the path (vitvs_v2.py:474-475) applied while the patch
+// rows are built — the resized image never exists in memory.  Workgroup = one token: the camera rows its
+// patch draws on are filtered horizontally, for the patch's columns only, into LDS (Pillow's intermediate image: uint8,
+// rounded and clipped as in Resample.c), then combined vertically, normalised and stored.  Same integer arithmetic as
+// resize_bicubic_kernel (resize.hip), so every pixel is the one PIL produces, bit for bit; a camera row is filtered again by
+// the ~1.5 patches above / below that share it (about 10 MFLOP of integer work per frame pair instead of a launch and a
+// round trip of the resized image).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_resize_kernel(PatchifyArgs a, ResizeArgs r, T* __restrict__ Ape,
+                                                              float* __restrict__ x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [rows][patch][3] intermediate pixels
+    const int Tn = a.grid * a.grid;
+    const int n_img = a.n_des + a.n_cur;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (row >= n_img * Tn) {  // cls rows: x[img][0][:] = cls + pos[0]
+        const int img = row - n_img * Tn;
+        float* dst = x + (size_t)img * (Tn + 1) * a.D;
+        for (int d = tid; d < a.D; d += blockDim.x) dst[d] = a.cls[d] + a.pos[d];
+        return;
+    }
+    const int img = row / Tn, t = row - img * Tn;
+    const int ty = t / a.grid, tx = t - ty * a.grid;
+    const size_t frame = (size_t)r.in_h * r.in_w * 3;
+    const uint8_t* im = (img < a.n_des) ? a.des + (size_t)img * frame : a.cur + (size_t)(img - a.n_des) * frame;
+    const int y0 = ty * a.stride, x0 = tx * a.stride, row3 = a.patch * 3;
+    const int ylast = y0 + a.patch - 1;
+    const int rmin = r.yb[2 * y0];
+    const int nrows = r.yb[2 * ylast] + r.yb[2 * ylast + 1] - rmin;   // <= r.rows: both bounds grow with y (checked on the host)
+    for (int idx = tid; idx < nrows * row3; idx += 256) {
+        const int rr = idx / row3, rem = idx - rr * row3;
+        const int px = rem / 3, c = rem - px * 3;
+        const int xx = x0 + px;
+        const int xmin = r.xb[2 * xx], xcnt = r.xb[2 * xx + 1];
+        const uint8_t* p = im + ((size_t)(rmin + rr) * r.in_w + xmin) * 3 + c;
+        const int* k = r.xk + xx * r.ksx;
+        int ss = 1 << (kResizePrecisionBits - 1);
+        for (int i = 0; i < xcnt; ++i) ss += (int)p[3 * i] * k[i];
+        smem[idx] = (unsigned char)resize_clip8(ss);
+    }
+    __syncthreads();
+    const int pp = a.patch * a.patch;
+    T* dst = Ape + (size_t)row * a.Kp;
+    for (int k = tid; k < a.Kp; k += 256) {
+        float v = 0.f;
+        if (k < 3 * pp) {
+            const int c = k / pp, rem = k - c * pp;
+            const int py = rem / a.patch, px = rem - py * a.patch;
+            const int y = y0 + py;
+            const int ymin = r.yb[2 * y] - rmin, ycnt = r.yb[2 * y + 1];
+            const int* kk = r.yk + y * r.ksy;
+            const unsigned char* col = smem + (ymin * a.patch + px) * 3 + c;
+            int ss = 1 << (kResizePrecisionBits - 1);
+            for (int i = 0; i < ycnt; ++i) ss += (int)col[i * row3] * kk[i];
+            v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)resize_clip8(ss), 255.0f), a.mean[c]), a.std[c]);
+        }
+        dst[k] = from_float<T>(v);
+    }
+}
+
+int launch_patchify(Precision p, const PatchifyArgs& a, const ResizeArgs* rs, void* Ape, float* x, hipStream_t stream) {
     const int n_img = a.n_des + a.n_cur;
     const int rows = n_img * a.grid * a.grid + n_img;
     if (rows <= 0 || a.Kp < 3 * a.patch * a.patch) return -2;
+    if (rs) {
+        const size_t lds = (size_t)rs->rows * a.patch * 3;
+        if (lds == 0 || lds > 64 * 1024) return -3;
+        if (p == PREC_F32)
+            launch(patchify_resize_kernel<float>, dim3(rows), dim3(256), lds, stream, a, *rs, (float*)Ape, x);
+        else if (p == PREC_F16)
+            launch(patchify_resize_kernel<f16>, dim3(rows), dim3(256), lds, stream, a, *rs, (f16*)Ape, x);
+        else
+            launch(patchify_resize_kernel<bf16>, dim3(rows), dim3(256), lds, stream, a, *rs, (bf16*)Ape, x);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (p == PREC_F32)
         launch(patchify_kernel<float>, dim3(rows), dim3(256), 0, stream, a, (float*)Ape, x);
     else if (p == PREC_F16)

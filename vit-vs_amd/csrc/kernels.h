@@ -100,9 +100,18 @@ struct PatchifyArgs {
     const float* cls;     // [D]
     const float* pos;     // [1+T][D]
 };
+// Camera-resolution frames ([in_h][in_w][3] instead of [S][S][3]): Pillow's 8-bit bicubic resample tables of
+// resize_coefficients() (resize.hip) for both axes, on the device.  rows = the most camera rows one patch's pixels draw on.
+struct ResizeArgs {
+    const int *xb, *xk, *yb, *yk;   // bounds [S][2] (first input sample, count) and fixed-point taps [S][ks] per axis
+    int in_h, in_w, ksx, ksy, rows;
+};
+constexpr int kResizePrecisionBits = 32 - 8 - 2;   // Pillow Resample.c: PRECISION_BITS
+__device__ __forceinline__ int resize_clip8(int v) { return min(max(v >> kResizePrecisionBits, 0), 255); }
 // Ape[(img*T + t)][k] = ((u8/255) - mean_c)/std_c for k = c*p*p + py*p + px (zero for k >= 3p²);
-// x[img*(T+1)][:] = cls + pos[0].
-int launch_patchify(Precision p, const PatchifyArgs& a, void* Ape, float* x, hipStream_t stream);
+// x[img*(T+1)][:] = cls + pos[0].  rs != nullptr: des / cur are camera frames and u8 is the pixel PIL's
+// Image.resize((S, S)) would produce (vitvs_v2.py:474-475), computed while the row is built.
+int launch_patchify(Precision p, const PatchifyArgs& a, const ResizeArgs* rs, void* Ape, float* x, hipStream_t stream);
 // out[m][:] = LayerNorm(x[m][:]) * gamma + beta, out in precision p.
 int launch_layernorm(Precision p, const float* x, const float* gamma, const float* beta, void* out, int M, int D,
                      float eps, hipStream_t stream);

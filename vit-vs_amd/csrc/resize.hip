@@ -17,9 +17,8 @@
 
 namespace vitvs {
 
-constexpr int kPrecisionBits = 32 - 8 - 2;   // Resample.c: PRECISION_BITS
-
-__device__ __forceinline__ int clip8(int v) { return min(max(v >> kPrecisionBits, 0), 255); }
+constexpr int kPrecisionBits = kResizePrecisionBits;
+__device__ __forceinline__ int clip8(int v) { return resize_clip8(v); }
 
 __global__ __launch_bounds__(256) void resize_bicubic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              const int* __restrict__ xb, const int* __restrict__ xk,

@@ -67,6 +67,7 @@ class Engine:
             rc = self.lib.vitvs_create(C.byref(c), C.byref(self.handle))
         if rc != 0:
             raise VitvsError(f"vitvs_create failed ({rc}): {_lib.last_error(None)}")
+        self.frame_size = (cfg.img_size, cfg.img_size)   # geometry of the frames the calls take (set_frame_size)
         self.tokens = self.lib.vitvs_tokens(self.handle)
         self.desc_dim = self.lib.vitvs_desc_dim(self.handle)
         assert self.tokens == cfg.tokens
@@ -114,10 +115,22 @@ class Engine:
             raise VitvsError("frames must be uint8 RGB, HWC")
         if t.dim() == 3:
             t = t.unsqueeze(0)
-        s = self.cfg.img_size
-        if tuple(t.shape[1:]) != (s, s, 3):
-            raise VitvsError(f"frames must be [n,{s},{s},3], got {tuple(t.shape)}")
+        fh, fw = self.frame_size
+        if tuple(t.shape[1:]) != (fh, fw, 3):
+            raise VitvsError(f"frames must be [n,{fh},{fw},3], got {tuple(t.shape)}")
         return t.to(self.device).contiguous()
+
+    def set_frame_size(self, height: Optional[int] = None, width: Optional[int] = None) -> "Engine":
+        """Declare the geometry of the frames handed to this engine from now on: camera frames uint8 [height, width, 3]
+        instead of [S, S, 3].  The reference's ``image.resize((S, S))`` (PIL bicubic, vitvs_v2.py:474-475) then happens
+        inside the launch that builds the patch rows (bit-identical to PIL, no resized image in memory).  No arguments:
+        back to frames at S x S."""
+        s = self.cfg.img_size
+        h, w = (0, 0) if height is None or (height, width) == (s, s) else (int(height), int(width))
+        rc = self.lib.vitvs_set_frame_size(self.handle, h, w)
+        self._check(rc, "vitvs_set_frame_size")
+        self.frame_size = (h, w) if h else (s, s)
+        return self
 
     # ------------------------------------------------------------------ seams
     def forward_tokens(self, frames) -> torch.Tensor:

@@ -45,7 +45,8 @@ def compute_velocity(engine: Engine, I_cur, I_des, Z, K=None, *, selection="orde
     engine's parameters).
     """
     one = lambda a: a[None] if torch.is_tensor(a) else np.asarray(a)[None]   # noqa: E731  (device tensors stay there)
-    v, st = compute_velocity_batch(engine, one(I_cur), one(I_des), None if Z is None else one(Z), K, selection=selection,
+    des = None if I_des is None else one(I_des)            # None: the goal cached by Engine.set_goal
+    v, st = compute_velocity_batch(engine, one(I_cur), des, None if Z is None else one(Z), K, selection=selection,
                                    generator=generator, num_pairs=num_pairs)
     return v[0], int(st[0])
 
@@ -207,13 +208,30 @@ class Controller:
             return arr
         return self.engine.resize_frames(arr)[0]
 
+    def _path_frames(self, *imgs):
+        """The frames as the engine takes them.  When all share one geometry (the usual case: one camera), the frames
+        themselves: ``Engine.set_frame_size`` makes the launch that builds the patch rows apply the reference's
+        ``image.resize((S, S))`` (vitvs_v2.py:474-475) on the way, bit-identical to PIL and without a resized image in
+        memory.  Mixed geometries: each frame resized on its own (``_resized``)."""
+        arrs = []
+        for img in imgs:
+            if hasattr(img, "convert") and not isinstance(img, np.ndarray):   # PIL image
+                img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+            arrs.append(img if torch.is_tensor(img) else np.asarray(img, dtype=np.uint8))
+        shapes = {tuple(a.shape[:2]) for a in arrs}
+        if len(shapes) == 1:
+            self.engine.set_frame_size(*shapes.pop())
+            return arrs
+        self.engine.set_frame_size()
+        return [self._resized(a) for a in arrs]
+
     # -- the hot path
     def detect_features(self):
         """→ ((s_uv_star, s_uv), sim_selected) with int arrays [num_pairs,2] in camera pixels, or (None, None).
         The 10th consecutive failure raises RuntimeError("Persistent feature detection failure")."""
         if self.latest_image is None:
             return None, None
-        cur, des = self._resized(self.latest_pil_image), self._resized(self.goal_image)
+        cur, des = self._path_frames(self.latest_pil_image, self.goal_image)
         depth = self.latest_image_depth
         # the law needs a depth image; detect_features itself does not, so feed a dummy one if it is missing
         z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
@@ -270,8 +288,9 @@ class Controller:
         if eng.max_rows < k:
             raise ValueError(f"engine.max_rows must be >= {k} for the rotation search")
         dev = eng.device
-        cur = torch.stack([torch.as_tensor(self._resized(f)).to(dev) for f in candidate_frames])
-        des = torch.as_tensor(self._resized(self.goal_image)).to(dev)[None]
+        frames = self._path_frames(self.goal_image, *candidate_frames)
+        des = torch.as_tensor(frames[0]).to(dev)[None]
+        cur = torch.stack([torch.as_tensor(f).to(dev) for f in frames[1:]])
         z = np.zeros((n, self.params.v_max, self.params.u_max), np.uint16)
         order = torch.stack([torch.randperm(eng.tokens, generator=generator) for _ in range(n)]).to(torch.int32)
         _, st = eng.compute_velocity(cur, des, z, self.params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order,
