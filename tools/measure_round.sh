@@ -26,6 +26,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 8 pairs per update: the 256-row GEMM tiles at 3152 rows and the batched short-sequence attention
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_p8 -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --pairs 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/rocprof_trace_p8.err ) || exit 1
+# ViT-L/14 518² (configs[4]): 2740 rows, 1370-token attention
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_l -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --config vitl14_518 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/rocprof_trace_l.err ) || exit 1
 python tools/vendor_compare.py > $O/vendor.txt 2> $O/vendor.err
 tools/launch_floor > $O/launch_floor.txt 2>&1
 tools/valu_rate > $O/valu_rate.txt 2>&1
@@ -33,6 +35,7 @@ tools/op_chain > $O/op_chain_bf16.txt 2>&1
 tools/big_ops > $O/big_ops.txt 2>&1
 tools/big_ops mid > $O/big_ops_mid.txt 2>&1
 tools/big_ops slices > $O/big_ops_slices.txt 2>&1
+VITVS_WEIGHT_MB=600 tools/big_ops > $O/big_ops_cold.txt 2>&1
 tools/big_ops sweep > $O/big_ops_k_sweep.txt 2>&1
 tools/big_ops attnmid > $O/attention_mid.txt 2>&1
 LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops attn > $O/attention_probe.txt 2>&1
@@ -43,7 +46,8 @@ cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bf16.csv
 python tools/trace_summary.py $(find $O/trace_b8 -name "*kernel_trace.csv" | head -1) > $O/trace_summary_bf16_vitb8_448.txt
 cp $(find $O/trace_b8 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bf16_vitb8_448.csv
 python tools/trace_summary.py $(find $O/trace_p8 -name "*kernel_trace.csv" | head -1) > $O/trace_summary_bf16_pairs8.txt
+python tools/trace_summary.py $(find $O/trace_l -name "*kernel_trace.csv" | head -1) > $O/trace_summary_bf16_vitl14_518.txt
 python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1) --commit "$COMMIT" --command "rocprofv3 --pmc <counter> -- $CMD" > $O/pmc_traffic.json
 python tools/pmc_summary.py $(find $O/pmcb8_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmcb8_WRITE_SIZE -name "*counter_collection.csv" | head -1) --commit "$COMMIT" --command "rocprofv3 --pmc <counter> -- python3 bench.py --config vitb8_448 --steps 5 --warmup 2 ..." > $O/pmc_traffic_vitb8_448.json
-rm -rf $O/trace $O/trace_b8 $O/trace_p8 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmcb8_FETCH_SIZE $O/pmcb8_WRITE_SIZE
+rm -rf $O/trace $O/trace_b8 $O/trace_p8 $O/trace_l $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmcb8_FETCH_SIZE $O/pmcb8_WRITE_SIZE
 tail -c 600 $O/bench_bf16.json
