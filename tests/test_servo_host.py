@@ -49,3 +49,55 @@ def test_ema_and_twist_match_reference_fixture():
     lin, ang = servo.twist_from_velocity([0.1, -0.2, 3.0, 0.4, -0.5, 0.6], 1.0)
     assert lin == (1.0, -0.1, 0.2) and ang == (0.6, -0.4, 0.5)
     assert (lin, ang) == sr.twist_remap([0.1, -0.2, 3.0, 0.4, -0.5, 0.6], 1.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's config.yaml schema (Controller.load_parameters, vitvs_v2.py:272-323)
+
+_CONFIG_KEYS = dict(u_max=1280, v_max=720, lambda_=0.01, min_error=100, max_error=70000, f_x=695.9951, f_y=695.9951,
+                    num_pairs=18, image_path="goal.jpg", dino_input_size=518, thresh_filter_keypoints=1,
+                    use_feature_binning=False, num_samples=500, num_circles=4, circle_radius_aug=0.08,
+                    velocity_convergence_threshold=8e-5, velocity_threshold_translation=5e-19,
+                    velocity_threshold_rotation=5e-19, error_threshold_ratio=0.001,
+                    error_threshold_absolute_translation=0.1, error_threshold_absolute_rotation=0.1, min_iterations=300,
+                    max_iterations=700)
+
+
+def test_reference_config_schema_is_read_like_load_parameters(tmp_path):
+    import yaml
+    from vitvs_amd import config
+    path = tmp_path / "config.yaml"
+    path.write_text(yaml.safe_dump(_CONFIG_KEYS))
+    rc = config.load_reference_config(str(path))
+    p = rc.servo
+    assert (p.u_max, p.v_max, p.num_pairs, p.dino_input_size, p.use_feature_binning) == (1280, 720, 18, 518, False)
+    assert p.intrinsics() == (695.9951, 695.9951, 640.0, 360.0)          # principal point = half the image (:282-283)
+    assert p.lambda_ == 0.01 and rc.max_iterations == 700 and rc.image_path == "goal.jpg"
+    # the optional keys and their defaults in the reference (:287, 316, 319) — ema_alpha falls back to 0.1, not 0.8
+    assert p.max_velocity == 1.0 and p.ema_alpha == 0.1 and rc.max_velocity_vector_history == 200
+    assert rc.extras["background_thresh"] == 0.5 and rc.extras["num_samples"] == 500 and "u_max" not in rc.extras
+    full = dict(_CONFIG_KEYS, ema_alpha=0.8, max_velocity=0.5, max_velocity_vector_history=50, background_thresh=0.005)
+    rc = config.load_reference_config(full)
+    assert rc.servo.ema_alpha == 0.8 and rc.servo.max_velocity == 0.5 and rc.max_velocity_vector_history == 50
+    for missing in ("f_x", "max_iterations", "num_circles", "image_path"):     # indexed with config[...]: KeyError there too
+        with pytest.raises(KeyError, match=missing):
+            config.load_reference_config({k: v for k, v in _CONFIG_KEYS.items() if k != missing})
+
+    class Stub:
+        max_velocity_vector_history = 200
+        max_iterations = 1500
+    ctl, loop = Stub(), Stub()
+    rc.apply(controller=ctl, loop=loop)
+    assert ctl.max_velocity_vector_history == 50 and loop.max_iterations == 700
+
+
+def test_shipped_reference_config_gives_the_package_defaults():
+    """In the build container only: the reference's own config.yaml parses to ServoParams' defaults (which cite it)."""
+    import os
+    from vitvs_amd import config
+    shipped = "/root/reference/catkin_ws/ibvs/config/config.yaml"
+    if not os.path.exists(shipped):
+        pytest.skip("the reference tree is not on this machine")
+    rc = config.load_reference_config(shipped)
+    assert rc.servo == config.ServoParams()
+    assert rc.max_iterations == 1500 and rc.max_velocity_vector_history == 200

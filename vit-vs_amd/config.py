@@ -176,3 +176,62 @@ class ServoParams:
 def grid_side(tokens: int) -> int:
     # reference: vitvs_v2.py:75 (int(np.sqrt(T)); square grids only)
     return int(math.sqrt(tokens))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's configuration file (catkin_ws/ibvs/config/config.yaml, read by Controller.load_parameters,
+# vitvs_v2.py:272-323): the data format on the caller's side of the path.
+_REQUIRED_KEYS = (   # load_parameters indexes these with config[...]: a missing one is a KeyError there and here
+    "u_max", "v_max", "f_x", "f_y", "lambda_", "min_error", "max_error", "num_pairs", "thresh_filter_keypoints",
+    "dino_input_size", "use_feature_binning", "num_samples", "num_circles", "circle_radius_aug",
+    "velocity_convergence_threshold", "velocity_threshold_translation", "velocity_threshold_rotation",
+    "error_threshold_ratio", "error_threshold_absolute_translation", "error_threshold_absolute_rotation",
+    "min_iterations", "max_iterations", "image_path")
+
+
+@dataclass
+class ReferenceConfig:
+    """What a ``config.yaml`` of the reference says, split by who reads it here."""
+    servo: ServoParams                      # the path: camera model, gain, pairs, input size, binning, EMA, clip
+    max_iterations: int                     # ServoLoop(max_iterations=...)                       (vitvs_v2.py:412)
+    max_velocity_vector_history: int        # Controller.max_velocity_vector_history              (vitvs_v2.py:627)
+    image_path: str                         # goal image, relative to the reference's script directory (:323)
+    extras: dict                            # loaded by the reference, never read on the path (sampling, thresholds ...)
+
+    def apply(self, controller=None, loop=None):
+        """Copy the run-loop settings onto a ``servo.Controller`` / ``loop.ServoLoop`` built from ``self.servo``."""
+        if controller is not None:
+            controller.max_velocity_vector_history = self.max_velocity_vector_history
+        if loop is not None:
+            loop.max_iterations = self.max_iterations
+        return self
+
+
+def load_reference_config(source) -> ReferenceConfig:
+    """``source``: path of a YAML file in the reference's schema, or the mapping ``yaml.safe_load`` returned.
+
+    Same required keys as ``Controller.load_parameters`` (a missing one raises ``KeyError`` naming it) and the same
+    defaults for the optional ones: ``max_velocity`` 1.0, ``ema_alpha`` 0.1 (NOT the 0.8 the shipped file sets),
+    ``max_velocity_vector_history`` 200, ``background_thresh`` 0.5 (vitvs_v2.py:287, 296, 316, 319)."""
+    if isinstance(source, dict):
+        cfg = dict(source)
+    else:
+        import yaml
+        with open(source, "r") as fh:
+            cfg = yaml.safe_load(fh)
+        if not isinstance(cfg, dict):
+            raise ValueError(f"{source}: not a mapping")
+    for key in _REQUIRED_KEYS:
+        if key not in cfg:
+            raise KeyError(key)
+    servo = ServoParams(u_max=int(cfg["u_max"]), v_max=int(cfg["v_max"]), f_x=float(cfg["f_x"]), f_y=float(cfg["f_y"]),
+                        lambda_=float(cfg["lambda_"]), num_pairs=int(cfg["num_pairs"]),
+                        dino_input_size=int(cfg["dino_input_size"]), use_feature_binning=bool(cfg["use_feature_binning"]),
+                        ema_alpha=float(cfg.get("ema_alpha", 0.1)), max_velocity=float(cfg.get("max_velocity", 1.0)))
+    used = {"u_max", "v_max", "f_x", "f_y", "lambda_", "num_pairs", "dino_input_size", "use_feature_binning", "ema_alpha",
+            "max_velocity", "max_iterations", "max_velocity_vector_history", "image_path"}
+    extras = {k: v for k, v in cfg.items() if k not in used}
+    extras.setdefault("background_thresh", 0.5)
+    return ReferenceConfig(servo=servo, max_iterations=int(cfg["max_iterations"]),
+                           max_velocity_vector_history=int(cfg.get("max_velocity_vector_history", 200)),
+                           image_path=str(cfg["image_path"]), extras=extras)
