@@ -168,6 +168,14 @@ VITVS_API int vitvs_extract_facet_dev(vitvs_handle* h, int32_t n_frames, const u
  * velocity path correlates).  Raw, un-normalised values, like vitvs_extract_descriptors_dev. */
 VITVS_API int vitvs_extract_descriptors_ex_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t facet, int32_t bin,
                                      int32_t include_cls, float* desc, void* stream);
+/* ViTExtractor.extract_saliency_maps(batch) (dinov2_extractor.py:339-353; the 'attn' facet, :230-231): the class token's
+ * attention over the patch tokens in blocks[layer] — softmax over all 1 + T keys, patch columns kept — averaged over the
+ * heads head_idxs (host array; the reference uses [0, 2, 4, 5] and supports dino_vits8 only) and min-max normalised per
+ * image (the reference's broadcast of the [B] extremes is only well-formed for a batch of one; every image gets its own):
+ * saliency fp32 [n][T] in [0, 1].  The handle must have been created with layer = the block wanted (the reference hooks
+ * block 11). */
+VITVS_API int vitvs_extract_saliency_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t n_heads,
+                               const int32_t* head_idxs, float* saliency, void* stream);
 /* Residual stream after block `cfg.blocks - 1`, fp32 [n][1+T][D] (what the forward hook captures,
  * dinov2_extractor.py:198-199), for parity tests. */
 VITVS_API int vitvs_forward_tokens_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, float* tokens, void* stream);

@@ -151,6 +151,33 @@ def extract_facet(sd, frames_u8, *, patch, stride, heads, layer, mean, std, face
     return f.unsqueeze(1)
 
 
+def cls_attention(sd, frames_u8, *, patch, stride, heads, layer, mean, std, eps: float = 1e-6) -> torch.Tensor:
+    """The 'attn' facet restricted to what the reference reads from it: attention probabilities of the class token in
+    ``blocks[layer]`` over the patch tokens, [B, H, T] (dinov2_extractor.py:230-231 hooks ``attn.attn_drop``, i.e. the
+    softmax output ``((q @ k^T) * hd^-0.5).softmax(-1)`` of shape B x H x N x N; :349 takes ``[:, heads, 0, 1:]``)."""
+    stages = block_tokens(sd, frames_u8, patch=patch, stride=stride, heads=heads, layer=layer, mean=mean, std=std,
+                          eps=eps, return_all=True)
+    x = stages[layer]                                        # input of blocks[layer]
+    p = f"blocks.{layer}."
+    d = x.shape[-1]
+    y = F.layer_norm(x, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    b, n, c = y.shape
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(b, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+    q, k = qkv[0], qkv[1]                                    # B x H x N x hd
+    attn = ((q @ k.transpose(-2, -1)) * (c // heads) ** -0.5).softmax(dim=-1)
+    return attn[:, :, 0, 1:]
+
+
+def saliency_maps(sd, frames_u8, *, patch, stride, heads, layer, mean, std, head_idxs=(0, 2, 4, 5), eps: float = 1e-6):
+    """``ViTExtractor.extract_saliency_maps`` (dinov2_extractor.py:339-353): mean of the chosen heads' class-token attention,
+    min-max normalised per image, [B, T].  (The reference subtracts a [B] vector from a [B, T] map, which broadcasts as
+    intended only for a batch of one — its only use; here every image is normalised by its own extremes.)"""
+    a = cls_attention(sd, frames_u8, patch=patch, stride=stride, heads=heads, layer=layer, mean=mean, std=std, eps=eps)
+    m = a[:, list(head_idxs)].mean(dim=1)
+    lo, hi = m.min(dim=1)[0], m.max(dim=1)[0]
+    return (m - lo[:, None]) / (hi - lo)[:, None]
+
+
 def log_bin(tokens: torch.Tensor, grid: int) -> torch.Tensor:
     """hierarchy=1 log-binning: for each cell the 3x3 neighbourhood tokens concatenated in
     row-major (dy,dx) order, replicate-clamped at the border (dinov2_extractor.py:289-308).

@@ -991,6 +991,46 @@ def test_extract_descriptors_facets(precision, tol, layerscale):
     assert "not supported together" in _lib.last_error(eng.handle)
 
 
+SALIENCY_BARS = {"fp32": 2e-4, "fp16": 3e-2, "bf16": 2e-1}     # max abs error of the [0, 1] map; measured 1.9e-5 / 1.6e-2 / 1.2e-1 (the
+# statistics are the stress fixture's, where bf16 tokens are off by 9e-2 per channel: STRESS_BARS; min-max normalisation stretches the row)
+
+
+@pytest.mark.parametrize("precision,stride", [("fp32", 8), ("fp16", 8), ("bf16", 8), ("fp32", 4)])
+def test_extract_saliency_maps(precision, stride):
+    """ViTExtractor.extract_saliency_maps (dinov2_extractor.py:339-353): class-token attention of block 11, heads
+    [0, 2, 4, 5], averaged and min-max normalised — dino_vits8 (the only model the reference allows) at 224 x 224, stride 8
+    (784 tokens) and the extractor's default stride 4 (3025 tokens), with peaked attention (trained-like statistics: with
+    trunc-normal(0.02) weights the row is uniform to 1e-4 and its min-max normalisation is noise)."""
+    from vitvs_amd.engine import VitvsError
+    cfg = config.vit_config("dino_vits8", 224, stride=stride)
+    sd = weights.trained_like_state_dict(cfg, 5)
+    eng = _engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision=precision,
+                  max_pairs=1).load_state_dict(sd)
+    frames = np.stack(synth.frame_pair(cfg.img_size, 99))
+    kw = dict(patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+    want = vit_ref.saliency_maps(sd, frames, **kw)
+    rows = vit_ref.cls_attention(sd, frames, **kw)[:, [0, 2, 4, 5]]
+    entropy = float(-(rows * rows.clamp_min(1e-30).log()).sum(-1).mean())
+    got = eng.extract_saliency_maps(frames).cpu()
+    assert got.shape == want.shape == (2, cfg.tokens)
+    assert float(got.min()) == 0.0 and float(got.max()) == 1.0
+    err = float((got - want).abs().max())
+    print(f"saliency {precision} stride {stride}: max abs err {err:.2e}; class-token row entropy {entropy:.2f} nats of {np.log(cfg.tokens + 1):.2f}")
+    assert err <= SALIENCY_BARS[precision]
+    for i in range(2):                                                   # the device's most salient token is the oracle's, up to the bar
+        assert float(want[i, got[i].argmax()]) >= 1.0 - SALIENCY_BARS[precision]
+    one = eng.extract_saliency_maps(frames[1]).cpu()                     # a batch of one, the reference's use (other row
+    assert float((one[0] - want[1]).abs().max()) <= SALIENCY_BARS[precision]   # count: the GEMMs sum in another order)
+    other = eng.extract_saliency_maps(frames, head_idxs=(1, 3)).cpu()
+    assert float((other - vit_ref.saliency_maps(sd, frames, head_idxs=(1, 3), **kw)).abs().max()) <= SALIENCY_BARS[precision]
+    with pytest.raises(VitvsError):
+        eng.extract_saliency_maps(frames, head_idxs=(0, 6))              # dino_vits8 has 6 heads
+    wrong = config.baseline_config("vits16_224")
+    eng2 = _engine(wrong, config.ServoParams(dino_input_size=224, use_feature_binning=False), precision="bf16", max_pairs=1)
+    with pytest.raises(AssertionError, match="supported only for dino_vits"):
+        eng2.extract_saliency_maps(frames)
+
+
 # ----------------------------------------------------------------------------------- size-independent properties
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_update_is_bit_reproducible_run_to_run(precision):

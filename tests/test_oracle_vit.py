@@ -83,6 +83,21 @@ def test_forward_matches_hf_vit():
     assert len(hs) == len(mine)
     for a, b in zip(hs, mine):
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+    # the 'attn' facet / saliency maps (dinov2_extractor.py:230-231, 339-353): the class token's attention row of the last
+    # block against the independent implementation's attention probabilities
+    model.config._attn_implementation = "eager"
+    with torch.no_grad():
+        att = model(pixel_values=x, output_attentions=True).attentions
+    if att is not None and att[cfg.layer] is not None:
+        kw = dict(patch=cfg.patch, stride=cfg.stride, heads=cfg.heads, layer=cfg.layer, mean=cfg.mean, std=cfg.std)
+        cls_rows = vit_ref.cls_attention(sd, frames, **kw)
+        assert cls_rows.shape == (2, cfg.heads, cfg.tokens)
+        assert float((cls_rows - att[cfg.layer][:, :, 0, 1:]).abs().max()) < 1e-6
+        sal = vit_ref.saliency_maps(sd, frames, head_idxs=(0, 1), **kw)
+        assert sal.shape == (2, cfg.tokens) and float(sal.min()) == 0.0 and float(sal.max()) == 1.0
+        want = att[cfg.layer][:, :, 0, 1:].mean(dim=1)
+        want = (want - want.min(dim=1)[0][:, None]) / (want.max(dim=1)[0] - want.min(dim=1)[0])[:, None]
+        assert float((sal - want).abs().max()) < 1e-4
 
 
 def test_forward_matches_hf_dinov2_layerscale():

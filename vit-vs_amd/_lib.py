@@ -64,6 +64,7 @@ PROTOTYPES = {
     "vitvs_extract_descriptors_ex_dev": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "vitvs_resize_frames_dev": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "vitvs_set_frame_size": (_I, [_P, _I, _I]),
+    "vitvs_extract_saliency_dev": (_I, [_P, _I, _P, _I, _P, _P, _P]),
     "vitvs_op_linear": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_variant": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_residual": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

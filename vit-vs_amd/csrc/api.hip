@@ -741,6 +741,21 @@ int vitvs_extract_descriptors_ex_dev(vitvs_handle* h, int32_t n_frames, const ui
     return 0;
 }
 
+int vitvs_extract_saliency_dev(vitvs_handle* h, int32_t n_frames, const uint8_t* frames, int32_t n_heads, const int32_t* head_idxs,
+                               float* saliency, void* stream) {
+    if (!h || !frames || !head_idxs || !saliency) return set_err(h, -1, "null argument");
+    if (n_heads <= 0 || n_heads > 16) return set_err(h, -5, "1 .. 16 heads");
+    for (int i = 0; i < n_heads; ++i)
+        if (head_idxs[i] < 0 || head_idxs[i] >= h->cfg.heads) return set_err(h, -5, "head index outside the model's heads");
+    DeviceScope dev(h);
+    hipStream_t st = as_stream(stream);
+    int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
+    if (rc) return rc;
+    rc = launch_saliency(h->prec, h->qkv, saliency, n_frames, h->T, h->cfg.heads, head_idxs, n_heads, h->prec != PREC_F32, st);
+    if (rc) return set_err(h, rc, rc == -3 ? "too many tokens for the saliency kernel's LDS rows" : "saliency launch failed");
+    return 0;
+}
+
 int vitvs_correspond_dev(vitvs_handle* h, int32_t T, int32_t Dp, const float* desc1, const float* desc2, int32_t* nn_1,
                          int32_t* nn_2, float* sim_1, float* S_out, void* stream) {
     if (!h || !desc1 || !desc2 || !nn_1 || !nn_2 || !sim_1) return set_err(h, -1, "null argument");

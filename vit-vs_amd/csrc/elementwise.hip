@@ -555,6 +555,87 @@ int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Saliency maps (ViTExtractor.extract_saliency_maps, dinov2_extractor.py:339-353: the 'attn' facet of the last block, hooked
+// behind attn_drop): the class token's attention row softmax(q_cls . K^T * hd^-0.5) over ALL 1 + T keys, patch columns only,
+// averaged over the chosen heads, then min-max normalised per image.  One workgroup per image; the row of each head is formed
+// in LDS (scores, max, exp, sum) — T + 1 dot products of 64 per head, nothing worth the matrix pipe.
+struct SaliencyHeads { int n; int idx[16]; };
+template <typename T>
+__global__ __launch_bounds__(256) void saliency_kernel(const T* __restrict__ qkv, float* __restrict__ out, int Tn, int H,
+                                                       SaliencyHeads heads, float scale, int base2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* row = reinterpret_cast<float*>(smem);          // [1 + T] scores, then probabilities of one head
+    float* acc = row + (Tn + 1);                          // [T] sum over the heads
+    __shared__ float red[8];
+    __shared__ float qs[64];
+    const int img = blockIdx.x, tid = threadIdx.x, N = Tn + 1, D = H * 64;
+    const T* base = qkv + (size_t)img * N * 3 * D;
+    for (int j = tid; j < Tn; j += 256) acc[j] = 0.f;
+    auto block_reduce = [&](float v, bool is_max) {
+        v = is_max ? wave_max(v) : wave_sum(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    for (int hi = 0; hi < heads.n; ++hi) {
+        const int h = heads.idx[hi];
+        __syncthreads();
+        if (tid < 64) qs[tid] = (float)base[h * 64 + tid];                        // q of the class token (row 0)
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int j = tid; j < N; j += 256) {
+            const T* k = base + (size_t)j * 3 * D + D + h * 64;
+            float s = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) s = fmaf(qs[d], (float)k[d], s);
+            s *= scale;
+            row[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = block_reduce(mx, true);
+        float sum = 0.f;
+        for (int j = tid; j < N; j += 256) {
+            const float e = base2 ? exp2f(row[j] - mx) : expf(row[j] - mx);
+            row[j] = e;
+            sum += e;
+        }
+        sum = block_reduce(sum, false);
+        for (int j = tid; j < Tn; j += 256) acc[j] += __fdiv_rn(row[j + 1], sum);
+    }
+    __syncthreads();
+    float lo = INFINITY, hi = -INFINITY;
+    for (int j = tid; j < Tn; j += 256) {
+        const float m = __fdiv_rn(acc[j], (float)heads.n);                        // .mean(dim=1)
+        acc[j] = m;
+        lo = fminf(lo, m);
+        hi = fmaxf(hi, m);
+    }
+    hi = block_reduce(hi, true);
+    lo = -block_reduce(-lo, true);
+    for (int j = tid; j < Tn; j += 256) out[(size_t)img * Tn + j] = __fdiv_rn(acc[j] - lo, hi - lo);
+}
+
+int launch_saliency(Precision p, const void* qkv, float* out, int n_img, int T, int H, const int* head_idx, int n_heads,
+                    bool q_prescaled, hipStream_t stream) {
+    if (n_img <= 0 || T <= 0 || H <= 0 || n_heads <= 0 || n_heads > 16) return -2;
+    SaliencyHeads hs;
+    hs.n = n_heads;
+    for (int i = 0; i < n_heads; ++i) {
+        if (head_idx[i] < 0 || head_idx[i] >= H) return -2;
+        hs.idx[i] = head_idx[i];
+    }
+    const size_t lds = (size_t)(2 * T + 1) * sizeof(float);
+    if (lds > 64 * 1024) return -3;
+    // 16-bit modes: the q rows of the qkv weights carry hd^-0.5 * log2(e) (kAttnQScale), so the scores are in log2 units
+    const float scale = q_prescaled ? 1.0f : 0.125f;
+    const int base2 = q_prescaled ? 1 : 0;
+    if (p == PREC_F32) launch(saliency_kernel<float>, dim3(n_img), dim3(256), lds, stream, (const float*)qkv, out, T, H, hs, scale, base2);
+    else if (p == PREC_F16) launch(saliency_kernel<f16>, dim3(n_img), dim3(256), lds, stream, (const f16*)qkv, out, T, H, hs, scale, base2);
+    else launch(saliency_kernel<bf16>, dim3(n_img), dim3(256), lds, stream, (const bf16*)qkv, out, T, H, hs, scale, base2);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
                        int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
                        hipStream_t stream) {

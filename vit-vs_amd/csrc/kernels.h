@@ -228,6 +228,10 @@ int launch_servo(const ServoArgs& a, hipStream_t stream);
 // keep_cls: 0 -> out [n_img][T][D]; 1 -> out [n_img][1 + T][D] (the cls row first)
 int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int H, int which, float q_unscale, int keep_cls,
                  hipStream_t stream);
+// Saliency maps of the extractor (dinov2_extractor.py:339-353): out fp32 [n_img][T], class-token attention of the chosen heads
+// of the block whose qkv is given, averaged and min-max normalised per image.
+int launch_saliency(Precision p, const void* qkv, float* out, int n_img, int T, int H, const int* head_idx, int n_heads,
+                    bool q_prescaled, hipStream_t stream);
 // Pillow-exact bicubic resize of n RGB uint8 frames [in_h][in_w][3] -> [out][out][3] (resize.hip).  The tables come from
 // resize_coefficients (host, double precision, Pillow's expressions): bounds [out][2] = (first tap, taps), coefficients
 // [out][ksize] in 22-bit fixed point; x tables for the width, y tables for the height.

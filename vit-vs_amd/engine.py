@@ -187,6 +187,20 @@ class Engine:
         self._check(rc, "vitvs_extract_descriptors_ex_dev")
         return out
 
+    def extract_saliency_maps(self, frames, head_idxs=(0, 2, 4, 5)) -> torch.Tensor:
+        """``ViTExtractor.extract_saliency_maps(batch)`` (dinov2_extractor.py:339-353): the class token's attention over the
+        patch tokens in block ``layer`` (the reference hooks block 11), averaged over ``head_idxs`` and min-max normalised per
+        image: float32 [n, T] in [0, 1].  Like the reference, only for ``dino_vits8`` (its assertion, same message)."""
+        assert self.cfg.model_type == "dino_vits8", "saliency maps are supported only for dino_vits model_type."
+        f = self._frames(frames)
+        n = f.shape[0]
+        heads = (C.c_int32 * len(head_idxs))(*[int(i) for i in head_idxs])
+        out = torch.empty((n, self.tokens), dtype=torch.float32, device=self.device)
+        rc = self.lib.vitvs_extract_saliency_dev(self.handle, n, _ptr(f), len(head_idxs), heads, _ptr(out),
+                                                 _stream_ptr(self.device))
+        self._check(rc, "vitvs_extract_saliency_dev")
+        return out
+
     def correspond(self, desc1: torch.Tensor, desc2: torch.Tensor, want_matrix: bool = False):
         """Similarity + argmax stage of find_correspondences_batch on [T,D] descriptors."""
         d1 = desc1.to(self.device, torch.float32).contiguous()
