@@ -49,6 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="vitb16_224")
     ap.add_argument("--selection", default="order", choices=["order", "dense"],
                     help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="independent updates in flight per GPU (handles x streams, vit-vs_amd/pipeline.py); 0 = the measured "
+                         "default: 4 up to a thousand rows per layer, 3 beyond; 1 = one stream, as in rounds 1-2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode leg")
     ap.add_argument("--no-plain-chain", action="store_true",
@@ -507,6 +510,18 @@ def run_rank(args):
     B = args.pairs
     dense = args.selection == "dense"
     eng = Engine(cfg, params, precision=args.precision, max_pairs=B, max_rows=cfg.tokens if dense else None).load_state_dict(sd)
+    # Updates of a throughput run do not depend on each other: `value` is measured with `in_flight` of them enqueued on as
+    # many streams through as many handles (vit-vs_amd/pipeline.py); the one-stream figure of the earlier rounds is reported
+    # beside it as `sequential`.
+    # default depth (profiles/r03_notes.md section 5): 4 while one update is at most a thousand rows per layer (3328 -> 3431
+    # updates/s from 3 to 4 at one ViT-B/16 pair), 3 beyond (8 pairs 8390, no gain from a fourth; 448² / 518² inputs are flat from 2)
+    in_flight = args.in_flight if args.in_flight > 0 else (4 if 2 * B * cfg.seq <= 1024 else 3)
+    pipe = None
+    if in_flight > 1:
+        from vitvs_amd.pipeline import UpdatePipeline
+        pipe = UpdatePipeline(cfg, params, sd, precision=args.precision, depth=in_flight, max_pairs=B,
+                              max_rows=cfg.tokens if dense else None, device=dev,
+                              stream_priority=int(os.environ.get("VITVS_PIPE_PRIORITY", "-1")))
 
     # per-rank synthetic inputs, resident in HBM.  The headline configuration draws its pairs from the accepted rig
     # seeds (rank r, pair i -> seed index (r * B + i) mod 8), so the 8-GPU run IS configs[3]'s 8-camera rig.
@@ -534,7 +549,7 @@ def run_rank(args):
     # GPU in a world of one rank that is SLOWER (0.577 vs 0.464 ms per update; no gather: 0.449): work of two queues
     # alternates on this platform instead of overlapping, so the second queue costs more than the wait it removes.
     async_gather = (multi and os.environ.get("VITVS_DIST_BACKEND", "nccl") == "nccl"
-                    and os.environ.get("VITVS_ASYNC_GATHER") == "1")
+                    and os.environ.get("VITVS_ASYNC_GATHER") == "1" and pipe is None)
     gather = vdist.VelocityGather(world * B, dev) if async_gather else None
     v_slots = [v, torch.zeros_like(v)]
 
@@ -564,8 +579,41 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    v_all_slots = [torch.zeros((world * B, 6), dtype=torch.float64, device=dev) for _ in range(in_flight)] if (multi and pipe) else None
+
+    def pipe_step(i):
+        if dense:
+            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False)
+        else:
+            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+        if multi:                                   # the update's v_c all-gather, behind it on its own stream
+            v_k, _, st_k = pipe.slot(t)
+            with torch.cuda.stream(st_k):
+                vdist.gather_velocities(v_k, world * B, out=v_all_slots[t % in_flight])
+
+    def pipe_fence():
+        pipe.synchronize()
+        fence()
+
+    sequential = None
     with torch.cuda.stream(stream):
-        elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
+        if pipe is not None:
+            for i in range(in_flight):              # every slot's graph is captured before anything is timed
+                pipe_step(i)
+            pipe_fence()
+            elapsed = timed_updates(None, pipe_step, pipe_fence, args.warmup, args.steps, dev)
+            last = (pipe.submitted - 1) % in_flight
+            v.copy_(pipe.v[last]); status.copy_(pipe.status[last])
+            if multi:
+                v_all.copy_(v_all_slots[last])
+            if world == 1:                          # the same updates one at a time on one stream (rounds 1-2's `value`)
+                el_seq = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
+                sequential = dict(metric="servo_updates_per_sec", value=round(B * args.steps / el_seq, 2), unit="updates/s",
+                                  steps=args.steps, warmup=args.warmup, ms_per_step=round(el_seq / args.steps * 1e3, 4),
+                                  note="one update in flight: one handle, one stream, plain launches (what `value` was in "
+                                       "rounds 1-2); the per-kernel table and the roofline object are measured in this form")
+        else:
+            elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
         if multi:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -748,14 +796,16 @@ def run_rank(args):
         vs_baseline=None, dtype=args.precision, data="synthetic",
         config=dict(workload=f"{cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair(s): both frames forwarded "
                              f"through block {cfg.layer}, cosine correspondence, mutual-NN, {params.num_pairs} features "
-                             f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update",
-                    key=args.config, pairs_per_step_per_gpu=B, tokens=cfg.tokens, dim=cfg.dim,
+                             f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update; "
+                             f"{B} pair(s) per update, {in_flight} independent update(s) in flight",
+                    key=args.config, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=in_flight, tokens=cfg.tokens, dim=cfg.dim,
                     parallelism=(f"dp{world} (frame pairs sharded, v_c all-gather per step"
                                  f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
                     weights="synthetic seed 0", frame_seeds=seeds, selection="DENSE" if dense else "ORDER"),
         roofline=roof,
         cpu_baseline=None,
         parity=parity,
+        sequential=sequential,
         secondary=secondary,
         goal_cached=goal_cached,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),

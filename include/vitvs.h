@@ -207,6 +207,21 @@ VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t*
 VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,
                        int32_t* selected, int32_t* s_uv, double* feat, double* L);
 
+/* --- several updates in flight ------------------------------------------------------------------
+ * One update at one frame pair is a chain of 86 dependent launches; each pays the device's launch-to-launch floor and its own
+ * ramp, so the chain leaves most of the chip idle most of the time.  Updates that do not depend on each other (several
+ * cameras / control loops sharing the GPU, or a frame stream run as a pipeline) overlap when they are enqueued through
+ * DIFFERENT handles on DIFFERENT streams: one call in flight per handle, any number of handles (vit-vs_amd/pipeline.py is
+ * that arrangement; measured: profiles/r03_notes.md section 5).  Per-handle options for it:
+ *   "graph_replay" 0 / 1   velocity calls replay a hipGraph captured per argument tuple (host cost ~50 us per update
+ *                          instead of ~370 us of launch calls, so ONE host thread keeps several streams busy; on a single
+ *                          stream plain launches are ~2 % faster, hence the default 0, or the VITVS_GRAPH environment variable
+ *                          at creation).  The reference has no counterpart (one torch call chain per update, vitvs_v2.py:464-523).
+ *   "in_flight"    n >= 1  a hint: this handle's updates run beside n - 1 others.  From 2 on the one-round GEMM launches
+ *                          use 4-wave workgroups (half the LDS: two launches of different queues share a CU).
+ * Returns 0, or -5 for an unknown name / a value out of range. */
+VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value);
+
 /* --- measurement hooks (bench.py roofline leg) --------------------------------------------------
  * With timing enabled every kernel of the path is dispatched with a HIP event pair that the dispatch
  * itself stamps with its begin / end times (hipExtLaunchKernelGGL on the launch stream; hipGraph replay

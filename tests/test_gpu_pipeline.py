@@ -1,0 +1,134 @@
+"""Several updates in flight (vit-vs_amd/pipeline.py, vitvs_set_option): the pipelined updates are the SAME computation
+as the one-stream call — bit-identical to it under the same tile plan, and within the parity bars of tests/test_gpu_path.py
+against the CPU oracle under the 4-wave plan the ``in_flight`` hint selects."""
+import numpy as np
+import pytest
+import torch
+
+import vitvs_amd  # noqa: F401
+from vitvs_amd import _lib, config, synth, weights
+from vitvs_amd.engine import Engine, VitvsError
+from vitvs_amd.pipeline import UpdatePipeline
+from conftest import golden_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(cfg, params, seeds, dev):
+    pairs = [synth.frame_pair(cfg.img_size, s) for s in seeds]
+    depth = synth.depth_pattern()
+    des = [torch.from_numpy(p[0][None]).to(dev) for p in pairs]
+    cur = [torch.from_numpy(p[1][None]).to(dev) for p in pairs]
+    Z = torch.from_numpy(depth[None]).to(dev)
+    K = torch.tensor([params.intrinsics()], dtype=torch.float64, device=dev)
+    return pairs, depth, des, cur, Z, K
+
+
+def _orders(cfg, n, dev, seed=121):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.randperm(cfg.tokens, generator=gen) for _ in range(n)]).to(torch.int32).to(dev)[:, None]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("hint", [False, True])
+def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint):
+    """11 updates over 4 different frame pairs and 11 visiting orders through a pipeline of depth 3 against the same updates,
+    one at a time, through a single handle with the same plan."""
+    dev = torch.device("cuda", 0)
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    seeds = synth.RIG8_FRAME_SEEDS[:4]
+    _, _, des, cur, Z, K = _inputs(cfg, params, seeds, dev)
+    n = 11
+    orders = _orders(cfg, n, dev)
+
+    eng = Engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    if hint:
+        eng.set_option("in_flight", 3)
+    want = []
+    for i in range(n):
+        v, s = eng.compute_velocity_dev(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i])
+        want.append((v.cpu().numpy().copy(), s.cpu().numpy().copy()))
+    assert all(int(s[0]) == _lib.STATUS_OK for _, s in want)
+    assert len({w[0].tobytes() for w in want}) > 4        # the updates really differ (pairs and orders)
+
+    pipe = UpdatePipeline(cfg, params, sd, precision=precision, depth=3, plan_hint=hint)
+    got = {}
+    tickets = []
+    for i in range(n):
+        tickets.append(pipe.submit(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i]))
+        if len(tickets) == 3:                                   # never more than `depth` unread results
+            t = tickets.pop(0)
+            got[t] = pipe.result(t)
+    for t in tickets:
+        got[t] = pipe.result(t)
+    for i in range(n):
+        v, s = got[i]
+        assert np.array_equal(v.cpu().numpy(), want[i][0]), f"update {i}"
+        assert np.array_equal(s.cpu().numpy(), want[i][1])
+    # a second pass replays the captured graphs: still the same bits
+    t2 = [pipe.submit(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i]) for i in range(3)]
+    for i, t in enumerate(t2):
+        assert np.array_equal(pipe.result(t)[0].cpu().numpy(), want[i][0])
+    pipe.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("key", ["vits16_224", "vitb16_224"])
+def test_in_flight_plan_meets_the_reference_fixture_in_fp32(key):
+    """The 4-wave GEMM plan changes only the summation order inside a GEMM's k-loop: against the reference-generated fixture the
+    fp32 mode keeps bit-exact arg-max tables and pixel features and v_c <= 1e-9 (north_star: 1e-4), exactly as
+    tests/test_gpu_path.py::test_compute_velocity_fp32_matches_reference asserts for the default plan."""
+    blob = load_golden(f"e2e_{key}.npz")
+    case = golden_case(blob, "plain")
+    cfg = config.baseline_config(key)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = Engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd).set_option("in_flight", 3)
+    sel = (case["points1"][:, 0] * cfg.grid + case["points1"][:, 1]).astype(np.int32)
+    v, st = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
+    det = eng.last_details(1)
+    assert int(st[0]) == 0
+    assert np.array_equal(det["nn_1"][0], case["nn_1"]) and np.array_equal(det["nn_2"][0], case["nn_2"])
+    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=2e-5)
+    k = case["s_uv"].shape[0]
+    assert np.array_equal(det["s_uv"][0, :k, 2:4], case["s_uv"]) and np.array_equal(det["s_uv"][0, :k, 0:2], case["s_uv_star"])
+    got, want = v.cpu().numpy()[0], case["v_c"]
+    assert np.linalg.norm(got - want) <= 1e-9 * np.linalg.norm(want)
+    eng.close()
+
+
+def test_tickets_options_and_cached_goal():
+    dev = torch.device("cuda", 0)
+    blob = load_golden("e2e_vitb16_224.npz")                    # an accepted pair: arg-max margins above the fp32 noise
+    cfg = config.baseline_config("vitb16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
+    _, _, des, cur, Z, K = _inputs(cfg, params, [int(blob["frame_seed"]), synth.RIG8_FRAME_SEEDS[1]], dev)
+    orders = _orders(cfg, 4, dev)
+    pipe = UpdatePipeline(cfg, params, sd, precision="fp32", depth=2)
+    with pytest.raises(VitvsError):
+        pipe.slot(0)                                            # nothing submitted yet
+    e = pipe.engines[0]
+    with pytest.raises(VitvsError, match="unknown option"):
+        e.set_option("no_such_option", 1)
+    with pytest.raises(VitvsError, match="in_flight"):
+        e.set_option("in_flight", 0)
+    with pytest.raises(VitvsError, match="graph_replay"):
+        e.set_option("graph_replay", 2)
+    # cached goal in every handle: I_des = None forwards only the current frame, on whichever slot the update lands
+    with_goal = [pipe.result(pipe.submit(cur[0], des[0], Z, K, _lib.SELECT_ORDER, orders[i]))[0].cpu().numpy() for i in range(2)]
+    pipe.set_goal(des[0])
+    cached = [pipe.result(pipe.submit(cur[0], None, Z, K, _lib.SELECT_ORDER, orders[i]))[0].cpu().numpy() for i in range(2)]
+    for a, b in zip(cached, with_goal):
+        assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)      # row count of the GEMMs differs: summation order only
+    # a ticket that has been overtaken by `depth` later submissions is refused
+    t0 = pipe.submit(cur[1], des[1], Z, K, _lib.SELECT_ORDER, orders[2])
+    pipe.submit(cur[1], des[1], Z, K, _lib.SELECT_ORDER, orders[3])
+    pipe.submit(cur[0], des[0], Z, K, _lib.SELECT_ORDER, orders[0])
+    with pytest.raises(VitvsError):
+        pipe.result(t0)
+    pipe.synchronize()
+    pipe.close()

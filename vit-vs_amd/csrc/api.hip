@@ -20,6 +20,7 @@ namespace vitvs {
 static thread_local std::string g_last_error;
 thread_local LaunchTiming g_launch_timing;
 thread_local int g_current_device = -1;
+thread_local int g_updates_in_flight = 1;
 
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
@@ -109,6 +110,7 @@ struct vitvs_handle {
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     bool use_graphs = false;
+    int in_flight = 1;        // vitvs_set_option "in_flight": updates expected to run beside this handle's (tile plan hint)
     int goal_frames = 0;      // goal frames whose tokens / descriptors are cached in rows [0, goal_frames) (vitvs_set_goal_dev)
 };
 
@@ -124,16 +126,19 @@ int set_err(vitvs_handle* h, int code, const std::string& msg) {
 // (include/vitvs.h: "a handle is bound to the HIP device that was current when it was created"); the caller's device is
 // restored on return.  The pointer-only operator hooks (vitvs_op_*) run on the caller's current device.
 struct DeviceScope {
-    int prev = -1;
+    int prev = -1, prev_hint = 1;
     bool switched = false;
     explicit DeviceScope(const vitvs_handle* h) {
+        prev_hint = g_updates_in_flight;
         (void)hipGetDevice(&prev);
         const int want = h ? h->device : prev;
         if (want != prev) switched = hipSetDevice(want) == hipSuccess;
         g_current_device = switched ? want : prev;
+        g_updates_in_flight = h ? h->in_flight : 1;   // the tile plan of this handle's launches (kernels.h)
     }
     ~DeviceScope() {
         if (switched) { (void)hipSetDevice(prev); g_current_device = prev; }
+        g_updates_in_flight = prev_hint;
     }
 };
 
@@ -993,6 +998,35 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
             for (size_t c = 0; c < 7; ++c) memset(L + (b * 7 + c) * 2 * R + 2 * n, 0, (2 * R - 2 * n) * 8);
     }
     return 0;
+}
+
+static void drop_graphs(vitvs_handle* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
+int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return set_err(h, -1, "null argument");
+    const std::string nm(name);
+    if (nm == "graph_replay") {
+        if (value != 0 && value != 1) return set_err(h, -5, "graph_replay takes 0 or 1");
+        h->use_graphs = value == 1;
+        return 0;
+    }
+    if (nm == "in_flight") {
+        if (value < 1 || value > 64) return set_err(h, -5, "in_flight takes 1 .. 64");
+        if ((int)value != h->in_flight) {       // captured updates hold the previous plan's launches
+            DeviceScope dev(h);
+            VITVS_HIP_CHECK(hipDeviceSynchronize());
+            drop_graphs(h);
+            h->in_flight = (int)value;
+        }
+        return 0;
+    }
+    return set_err(h, -5, "unknown option " + nm);
 }
 
 int vitvs_timing_enable(vitvs_handle* h, int32_t on) {

@@ -218,7 +218,12 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
         if (best < 0) bn = (N % 128 == 0) ? 128 : 64;
     }
     const long wgs = mt * (N / bn) * splits;
-    const int kg = (wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
+    // Alone on the chip a one-round launch wants its serial k-loop short: two k-groups (8 waves, 112-144 KB of LDS, one
+    // workgroup per CU).  Beside the launches of other queues (several updates in flight, vitvs_set_option) that footprint
+    // keeps a second launch's workgroups off the CU until the first has left; 4-wave workgroups (64-80 KB) let two launches
+    // share it: ViT-B/16 224², 3 updates in flight 3113 -> 3392 updates/s, but 2220 -> 2078 on one stream (same box,
+    // profiles/r03_notes.md section 5), hence by the caller's hint and not by default.
+    const int kg = (g_updates_in_flight < 2 && wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
     return TilePlan{bn, kg};
 }
 

@@ -56,7 +56,13 @@ struct GemmTile {
     // workgroups per CU, measured -24 ... -27 % on the 6274-row fc1 / qkv GEMMs against 4 stages (1 workgroup per CU).
     // NS > 0 overrides the depth: the launchers of gemm.hip pick a shallower ring for 64-row launches of more than one
     // workgroup per CU, where the LDS footprint decides how many are resident (ring_stages() there has the measurements).
-    static constexpr int NST = NS ? NS : ((BM >= 128) ? 2 : ((KG == 1) ? 4 : 3));
+#ifndef VITVS_KG2_STAGES                      // experiments (tools/two_streams.py): ring depth of the two-k-group tiles
+#define VITVS_KG2_STAGES 3
+#endif
+#ifndef VITVS_LDS_CAP                         // ... and the footprint above which the swap area reuses the rings
+#define VITVS_LDS_CAP (160 * 1024)
+#endif
+    static constexpr int NST = NS ? NS : ((BM >= 128) ? 2 : ((KG == 1) ? 4 : VITVS_KG2_STAGES));
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
     static constexpr int RING_BYTES = KG * GROUP_BYTES;
@@ -64,7 +70,7 @@ struct GemmTile {
     // needed before the swap's writes while other waves still read their last stage)
     static constexpr int SWAP_SLOTS = (NT * MT + 1) / 2;            // accumulator tiles a wave hands over
     static constexpr int SWAP_BYTES = (KG == 2) ? SWAP_SLOTS * 16 * 512 : 0;
-    static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > 160 * 1024;   // no room: reuse the rings (one more barrier)
+    static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > VITVS_LDS_CAP;   // no room: reuse the rings (one more barrier)
     static constexpr int SWAP_OFFSET = SWAP_ALIAS ? 0 : RING_BYTES;
     static constexpr int LDS_BYTES = SWAP_ALIAS ? (RING_BYTES > SWAP_BYTES ? RING_BYTES : SWAP_BYTES) : RING_BYTES + SWAP_BYTES;
     static constexpr int THREADS = 256 * KG;

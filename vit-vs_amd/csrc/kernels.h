@@ -36,6 +36,10 @@ inline void launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stre
     }
 }
 
+// Updates the calling handle expects to run beside its own (vitvs_set_option "in_flight"; set by api.hip around a handle's
+// launches, 1 otherwise).  From 2 on the one-round GEMM launches of gemm.hip use 4-wave workgroups (plan_tiles).
+extern thread_local int g_updates_in_flight;
+
 // The HIP device the calling thread's current entry point runs on (set by the C-ABI layer's DeviceScope; api.hip).
 extern thread_local int g_current_device;
 inline int current_device() {

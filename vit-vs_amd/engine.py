@@ -318,6 +318,12 @@ class Engine:
         sel, cnt = self._selection_args(mode, selection, n, self.tokens, k)
         return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared, num_pairs=k)
 
+    # ------------------------------------------------------------------ options
+    def set_option(self, name: str, value: int) -> "Engine":
+        """Per-handle options of include/vitvs.h: ``graph_replay`` (0 / 1), ``in_flight`` (updates run beside this handle's)."""
+        self._check(self.lib.vitvs_set_option(self.handle, name.encode(), int(value)), f"vitvs_set_option({name})")
+        return self
+
     # ------------------------------------------------------------------ measurement hooks
     def timing_enable(self, on: bool = True):
         self._check(self.lib.vitvs_timing_enable(self.handle, int(on)), "vitvs_timing_enable")

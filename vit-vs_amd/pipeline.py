@@ -1,0 +1,111 @@
+"""Several independent servo updates in flight on one GPU.
+
+One update at one frame pair is a chain of 86 dependent launches that leaves most of the chip idle most of the time (each
+launch pays the launch-to-launch floor and its own ramp).  Updates that do not depend on each other — several cameras or
+control loops sharing the GPU, or a frame stream handled as a pipeline — overlap when they are enqueued through different
+handles on different HIP streams (measured on MI355X, ViT-B/16 224², bf16: 2220 updates/s on one stream, 2830 / 3110 with
+2 / 3 in flight, 3390 with the 4-wave GEMM plan the ``in_flight`` hint selects; profiles/r03_notes.md section 5).
+
+``UpdatePipeline`` is that arrangement: ``depth`` handles (each with its own weights copy and workspaces: one call in
+flight per handle, include/vitvs.h) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
+makes cheap enough (~50 us of host time per update).  Every update is the same computation as ``Engine.compute_velocity_dev``
+— the reference's ``detect_features`` + ``ibvs`` up to the raw twist (vitvs_v2.py:464-523, 588-622) — and its results
+are bit-identical to the one-stream call's with the same plan (tests/test_gpu_pipeline.py).
+
+PyTorch is plumbing here (streams, events, device buffers); all arithmetic runs in libvitvs_hip.so.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .config import ServoParams, ViTConfig
+from .engine import Engine, VitvsError
+
+
+class UpdatePipeline:
+    """``depth`` updates in flight.  ``submit`` enqueues one update and returns a ticket; ``result(ticket)`` waits for that
+    update alone.  A slot's output buffers are reused every ``depth`` submissions: read (or ``result``) a ticket before
+    submitting ``depth`` more."""
+
+    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "bf16", depth: int = 3,
+                 max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
+                 plan_hint: bool = True, stream_priority: int = -1):
+        if depth < 1:
+            raise VitvsError("depth must be >= 1")
+        self.depth = int(depth)
+        self.engines: List[Engine] = []
+        for _ in range(self.depth):
+            e = Engine(cfg, params, precision=precision, max_pairs=max_pairs, max_rows=max_rows, device=device)
+            e.load_state_dict(state_dict)
+            e.set_option("graph_replay", int(graph_replay))
+            if plan_hint:
+                e.set_option("in_flight", self.depth)
+            self.engines.append(e)
+        self.device = self.engines[0].device
+        # HIP hands out hardware queues per priority class (GPU_MAX_HW_QUEUES = 4 of each by default) and lets further
+        # streams of a class SHARE them: streams of the default class compete with the caller's, torch's and RCCL's streams for
+        # the same four queues, and two slots that land on one queue run one after the other (measured: depth 3 at 2500
+        # instead of 3300 updates/s, depending on what else the process had created).  High-priority streams draw from a pool
+        # of their own, so up to four slots always get a queue each.
+        self.streams = [torch.cuda.Stream(device=self.device, priority=stream_priority) for _ in range(self.depth)]
+        self.done = [torch.cuda.Event() for _ in range(self.depth)]
+        n = max_pairs
+        self.v = [torch.zeros((n, 6), dtype=torch.float64, device=self.device) for _ in range(self.depth)]
+        self.status = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
+        self.submitted = 0
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    # ------------------------------------------------------------------ enqueue
+    def submit(self, I_cur: torch.Tensor, I_des: Optional[torch.Tensor], Z: Optional[torch.Tensor], K: torch.Tensor,
+               mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
+               n_selected: Optional[torch.Tensor] = None, des_shared: bool = False, num_pairs: int = 0) -> int:
+        """Arguments as ``Engine.compute_velocity_dev`` (device tensors).  The slot's stream first waits for the caller's
+        current stream, so inputs produced there are complete; nothing synchronises the host."""
+        t = self.submitted
+        k = t % self.depth
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            self.engines[k].compute_velocity_dev(I_cur, I_des, Z, K, mode, selection, n_selected, des_shared,
+                                                 self.v[k], self.status[k], num_pairs)
+            self.done[k].record(st)
+        self.submitted = t + 1
+        return t
+
+    def set_goal(self, I_des: torch.Tensor):
+        """Cache the goal frame(s) in every handle (``Engine.set_goal``): later ``submit(..., I_des=None, ...)``."""
+        for k, e in enumerate(self.engines):
+            self.streams[k].wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.streams[k]):
+                e.set_goal(I_des)
+
+    # ------------------------------------------------------------------ collect
+    def slot(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Stream]:
+        """Output buffers (v_c [n, 6] float64, status [n] int32) and stream of ``ticket`` without waiting."""
+        if not (self.submitted - self.depth <= ticket < self.submitted):
+            raise VitvsError(f"ticket {ticket} is not in flight (submitted {self.submitted}, depth {self.depth})")
+        k = ticket % self.depth
+        return self.v[k], self.status[k], self.streams[k]
+
+    def result(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Wait (host) for ``ticket`` and return copies of its ``v_c`` and ``status``."""
+        v, s, _ = self.slot(ticket)
+        self.done[ticket % self.depth].synchronize()
+        return v.clone(), s.clone()
+
+    def join(self, stream: Optional[torch.cuda.Stream] = None):
+        """Make ``stream`` (default: the current one) wait for everything submitted so far (device-side)."""
+        stream = stream or torch.cuda.current_stream(self.device)
+        for k in range(min(self.depth, self.submitted)):
+            stream.wait_event(self.done[k])
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
