@@ -221,6 +221,11 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
  *                          use 4-wave workgroups (half the LDS: two launches of different queues share a CU).
  * Returns 0, or -5 for an unknown name / a value out of range. */
 VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value);
+/* The handles of such an arrangement run ONE network: `h` (created with the same network, input geometry and precision, no
+ * tensors uploaded) borrows the device weights of `src` instead of holding a copy — one set of weights stays resident in
+ * the Infinity Cache for all queues (a copy per handle: 4 x 172 MB cycle through its 256 MB).  `src` must own its weights,
+ * have all of them (vitvs_weights_ready) and outlive `h`; uploads go to `src` only (vitvs_set_tensor on `h` is error -5). */
+VITVS_API int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src);
 
 /* --- measurement hooks (bench.py roofline leg) --------------------------------------------------
  * With timing enabled every kernel of the path is dispatched with a HIP event pair that the dispatch

@@ -118,6 +118,18 @@ def test_tickets_options_and_cached_goal():
         e.set_option("in_flight", 0)
     with pytest.raises(VitvsError, match="graph_replay"):
         e.set_option("graph_replay", 2)
+    # the slots borrow slot 0's weights (vitvs_share_weights): uploads go to the owner only, and only like shares with like
+    sd_np = {k: v for k, v in sd.items()}
+    with pytest.raises(VitvsError, match="borrows"):
+        pipe.engines[1].load_state_dict(sd_np)
+    other = Engine(cfg, params, precision="bf16", max_pairs=1)
+    with pytest.raises(VitvsError, match="precision"):
+        other.share_weights(pipe.engines[0])
+    other.close()
+    fresh = Engine(cfg, params, precision="fp32", max_pairs=1)
+    with pytest.raises(VitvsError, match="owns"):
+        fresh.share_weights(pipe.engines[1])                    # a borrower cannot lend
+    fresh.close()
     # cached goal in every handle: I_des = None forwards only the current frame, on whichever slot the update lands
     with_goal = [pipe.result(pipe.submit(cur[0], des[0], Z, K, _lib.SELECT_ORDER, orders[i]))[0].cpu().numpy() for i in range(2)]
     pipe.set_goal(des[0])

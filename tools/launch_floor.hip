@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -127,7 +128,74 @@ static void run_queued(const char* name, int reps, hipStream_t st, float* buf, F
     printf("%-44s queued behind a blocker %6.2f us/launch   graph replay %6.2f us/launch\n", name, best * 1e3 / reps, gbest * 1e3 / reps);
 }
 
-int main() {
+// every wave sleeps ~`us` microseconds without touching memory, LDS or the vector pipes: a stand-in for a launch whose
+// body is latency (what a one-pair GEMM launch is), so that k chains can only be limited by dispatch, not by resources
+__global__ void k_sleep(float* p, unsigned ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(2);
+    if (p == nullptr) p[0] = 1.f;
+}
+
+// k chains of `reps` dependent launches, one chain per high-priority stream (a queue each), replayed as graphs at the same
+// time: the AGGREGATE dispatch rate of the command processor (does the 1.76 us launch-to-launch floor of one queue overlap
+// across queues?)
+static void run_queues(const char* name, int reps, int k, dim3 grid, dim3 block, unsigned sleep_ticks, float* buf,
+                       int copy_n4 = 0, int lds = 0) {
+    int lo = 0, hi = 0;
+    CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    std::vector<hipStream_t> st(k);
+    std::vector<hipGraphExec_t> ge(k);
+    for (int q = 0; q < k; ++q) {
+        CHECK(hipStreamCreateWithPriority(&st[q], hipStreamNonBlocking, hi));
+        hipGraph_t g;
+        CHECK(hipStreamBeginCapture(st[q], hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < reps; ++i) {
+            if (copy_n4) {                    // a load -> store row pass per launch, ping-pong between two buffers of this queue
+                float4* a = reinterpret_cast<float4*>(buf) + (size_t)(2 * q) * copy_n4;
+                float4* b = a + copy_n4;
+                hipLaunchKernelGGL(k_copy, dim3((copy_n4 + 255) / 256), dim3(256), 0, st[q], (i & 1) ? b : a, (i & 1) ? a : b, copy_n4);
+            } else if (lds) hipLaunchKernelGGL(k_lds, grid, block, lds, st[q], buf);
+            else if (sleep_ticks) hipLaunchKernelGGL(k_sleep, grid, block, 0, st[q], buf, sleep_ticks);
+            else hipLaunchKernelGGL(k_empty, grid, block, 0, st[q], buf);
+        }
+        CHECK(hipStreamEndCapture(st[q], &g));
+        CHECK(hipGraphInstantiate(&ge[q], g, nullptr, nullptr, 0));
+        CHECK(hipGraphLaunch(ge[q], st[q]));
+    }
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int round = 0; round < 3; ++round) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int rep = 0; rep < 4; ++rep)
+            for (int q = 0; q < k; ++q) CHECK(hipGraphLaunch(ge[q], st[q]));
+        CHECK(hipDeviceSynchronize());
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        if (us < best) best = us;
+    }
+    printf("%-36s %d queue(s): %6.2f us per launch per queue, %6.2f us per launch overall\n", name, k, best / (4.0 * reps),
+           best / (4.0 * reps * k));
+    for (int q = 0; q < k; ++q) { CHECK(hipGraphExecDestroy(ge[q])); CHECK(hipStreamDestroy(st[q])); }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'q') {          // launch_floor queues
+        float* buf; CHECK(hipMalloc(&buf, 4096));
+        for (int k = 1; k <= 4; ++k) run_queues("empty 256 x 64", 400, k, dim3(256), dim3(64), 0, buf);
+        for (int k = 1; k <= 4; ++k) run_queues("empty 252 x 256", 400, k, dim3(252), dim3(256), 0, buf);
+        for (int k = 1; k <= 4; ++k) run_queues("sleep 3 us 252 x 256", 400, k, dim3(252), dim3(256), 300, buf);
+        for (int k = 1; k <= 4; ++k) run_queues("sleep 3 us 1 x 64", 400, k, dim3(1), dim3(64), 300, buf);
+        for (int k = 1; k <= 4; ++k) run_queues("sleep 10 us 252 x 256", 200, k, dim3(252), dim3(256), 1000, buf);
+        const int n4 = 394 * 768 / 4;
+        float* big; CHECK(hipMalloc(&big, (size_t)8 * n4 * 16 * 4)); CHECK(hipMemset(big, 0, (size_t)8 * n4 * 16 * 4));
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int k = 1; k <= 4; ++k) run_queues("copy 1.2 MB 296 x 256 (ping-pong)", 400, k, dim3(1), dim3(1), 0, big, n4);
+        for (int k = 1; k <= 4; ++k) run_queues("copy 4.8 MB (ping-pong)", 400, k, dim3(1), dim3(1), 0, big, 4 * n4);
+        for (int k = 1; k <= 4; ++k) run_queues("empty, 112 KB LDS 252 x 512", 400, k, dim3(252), dim3(512), 0, buf, 0, 112 * 1024);
+        for (int k = 1; k <= 4; ++k) run_queues("empty, 64 KB LDS 252 x 256", 400, k, dim3(252), dim3(256), 0, buf, 0, 64 * 1024);
+        return 0;
+    }
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
     const int n4 = 394 * 768 / 4;   // one fp32 activation matrix of the headline workload

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <functional>
+#include <time.h>
+#include <vector>
 
 #include "vitvs.h"
 #include "vitvs_ops.h"
@@ -38,7 +40,87 @@ static void run(const char* name, hipStream_t st, int reps, const std::function<
     printf("%-44s %6.2f us/launch\n", name, best * 1e3 / reps);
 }
 
+// `tools/op_chain queues`: the same operators as chains on k = 1 .. 3 high-priority streams (a hardware queue each, own
+// activations, shared rotating weights), captured as graphs and replayed at the same time: which launches of the forward
+// overlap with their like on another queue, and which only take turns?
+struct Acts { void *xn, *qkv, *attn, *hid; float *x, *part; };
+static int queues_mode(int prec) {
+    const size_t es = prec == VITVS_F32 ? 4 : 2;
+    const int M = 394, D = 768, H = 12, N = 197, hidden = 3072, reps = 240;
+    int lo = 0, hi = 0;
+    CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t st[3];
+    Acts a[3];
+    for (int q = 0; q < 3; ++q) {
+        CHECK(hipStreamCreateWithPriority(&st[q], hipStreamNonBlocking, hi));
+        a[q] = Acts{dalloc((size_t)M * D * es, 0), dalloc((size_t)M * 3 * D * es, 0), dalloc((size_t)M * D * es, 0),
+                    dalloc((size_t)M * hidden * es, 0), (float*)dalloc((size_t)M * D * 4, 0), (float*)dalloc((size_t)8 * M * D * 4, 0)};
+    }
+    void *wqkv[12], *wproj[12], *wfc1[12], *wfc2[12];
+    for (int b = 0; b < 12; ++b) {
+        wqkv[b] = dalloc((size_t)3 * D * D * es, 0); wproj[b] = dalloc((size_t)D * D * es, 0);
+        wfc1[b] = dalloc((size_t)hidden * D * es, 0); wfc2[b] = dalloc((size_t)D * hidden * es, 0);
+    }
+    float* bias = (float*)dalloc((size_t)hidden * 4, 0);
+    float* gamma = (float*)dalloc((size_t)D * 4, 0);
+    float* beta = (float*)dalloc((size_t)D * 4, 0);
+    const int s_proj = vitvs_op_splitk_slices(prec, M, D, D), s_fc2 = vitvs_op_splitk_slices(prec, M, D, hidden);
+    struct Op { const char* name; int launches; std::function<int(int, int)> f; };   // f(queue, i)
+    std::vector<Op> ops = {
+        {"qkv   linear 394x2304x768", 1, [&](int q, int i) { return vitvs_op_linear(prec, a[q].xn, wqkv[i % 12], bias, a[q].qkv, M, 3 * D, D, 0, st[q]); }},
+        {"attention 2 x 12 heads x 197", 1, [&](int q, int) { return vitvs_op_attention(prec, a[q].qkv, a[q].attn, 2, N, H, st[q]); }},
+        {"proj  partial 394x768x768", 1, [&](int q, int i) { return vitvs_op_linear_partial(prec, a[q].attn, wproj[i % 12], a[q].part, M, D, D, s_proj, st[q]); }},
+        {"residual_ln (3 slices) + LayerNorm", 1, [&](int q, int) { return vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_fc2, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]); }},
+        {"fc1   linear+GELU 394x3072x768", 1, [&](int q, int i) { return vitvs_op_linear(prec, a[q].xn, wfc1[i % 12], bias, a[q].hid, M, hidden, D, 1, st[q]); }},
+        {"fc2   partial 394x768x3072", 1, [&](int q, int i) { return vitvs_op_linear_partial(prec, a[q].hid, wfc2[i % 12], a[q].part, M, D, hidden, s_fc2, st[q]); }},
+        {"block (7 launches)", 7, [&](int q, int i) {
+            int rc = vitvs_op_linear(prec, a[q].xn, wqkv[i % 12], bias, a[q].qkv, M, 3 * D, D, 0, st[q]);
+            rc |= vitvs_op_attention(prec, a[q].qkv, a[q].attn, 2, N, H, st[q]);
+            rc |= vitvs_op_linear_partial(prec, a[q].attn, wproj[i % 12], a[q].part, M, D, D, s_proj, st[q]);
+            rc |= vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_proj, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]);
+            rc |= vitvs_op_linear(prec, a[q].xn, wfc1[i % 12], bias, a[q].hid, M, hidden, D, 1, st[q]);
+            rc |= vitvs_op_linear_partial(prec, a[q].hid, wfc2[i % 12], a[q].part, M, D, hidden, s_fc2, st[q]);
+            rc |= vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_fc2, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]);
+            return rc; }},
+    };
+    printf("%-40s %28s %28s %28s\n", "us per launch: per queue / overall", "1 queue", "2 queues", "3 queues");
+    for (auto& op : ops) {
+        const int n = op.launches == 7 ? reps / 4 : reps;
+        hipGraphExec_t ge[3];
+        for (int q = 0; q < 3; ++q) {
+            op.f(q, 0);                                  // LDS opt-in attributes are set outside the capture
+            CHECK(hipStreamSynchronize(st[q]));
+            hipGraph_t g;
+            CHECK(hipStreamBeginCapture(st[q], hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < n; ++i) if (op.f(q, i + 4 * q)) { printf("launch failed\n"); return 1; }
+            CHECK(hipStreamEndCapture(st[q], &g));
+            CHECK(hipGraphInstantiate(&ge[q], g, nullptr, nullptr, 0));
+        }
+        printf("%-40s", op.name);
+        for (int k = 1; k <= 3; ++k) {
+            double best = 1e30;
+            for (int round = 0; round < 4; ++round) {
+                CHECK(hipDeviceSynchronize());
+                timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (int rep = 0; rep < 3; ++rep)
+                    for (int q = 0; q < k; ++q) CHECK(hipGraphLaunch(ge[q], st[q]));
+                CHECK(hipDeviceSynchronize());
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+                if (round && us < best) best = us;
+            }
+            const double per = best / (3.0 * n * op.launches);
+            printf("        %8.2f / %8.2f", per, per / k);
+        }
+        printf("\n");
+        for (int q = 0; q < 3; ++q) CHECK(hipGraphExecDestroy(ge[q]));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'q') return queues_mode(VITVS_BF16);
     const int prec = (argc > 1 && atoi(argv[1]) == 32) ? VITVS_F32 : VITVS_BF16;
     const size_t es = prec == VITVS_F32 ? 4 : 2;
     const int M = 394, D = 768, H = 12, N = 197, hidden = 3072;

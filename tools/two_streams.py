@@ -25,7 +25,10 @@ from vitvs_amd.engine import Engine
 
 def make(cfg, params, sd, graph, prec="bf16", pairs=1):
     os.environ["VITVS_GRAPH"] = "1" if graph else "0"
-    return Engine(cfg, params, precision=prec, max_pairs=pairs).load_state_dict(sd)
+    e = Engine(cfg, params, precision=prec, max_pairs=pairs).load_state_dict(sd)
+    if os.environ.get("TOOL_IN_FLIGHT"):
+        e.set_option("in_flight", int(os.environ["TOOL_IN_FLIGHT"]))
+    return e
 
 
 def main():
@@ -85,7 +88,7 @@ def main():
         dt = time.perf_counter() - t0
         return n / dt, 0.0, [o[0].cpu().numpy().copy() for o in outs]
 
-    s = [torch.cuda.Stream(device=dev) for _ in range(6)]
+    s = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(6)]   # a hardware queue each (vit-vs_amd/pipeline.py)
     res = {}
     e_eager = [make(cfg, params, sd, False) for _ in range(4)]
     e_graph = [make(cfg, params, sd, True) for _ in range(6)]

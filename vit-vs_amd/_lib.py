@@ -55,6 +55,7 @@ PROTOTYPES = {
     "vitvs_servo_from_nn_dev": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "vitvs_last_details": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vitvs_set_option": (_I, [_P, C.c_char_p, C.c_int64]),
+    "vitvs_share_weights": (_I, [_P, _P]),
     "vitvs_timing_enable": (_I, [_P, _I]),
     "vitvs_timing_classes": (_I, []),
     "vitvs_timing_class_name": (C.c_char_p, [_I]),

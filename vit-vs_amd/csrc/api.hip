@@ -110,6 +110,7 @@ struct vitvs_handle {
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     bool use_graphs = false;
+    bool borrowed = false;    // weights belong to another handle (vitvs_share_weights): never uploaded to, never freed here
     int in_flight = 1;        // vitvs_set_option "in_flight": updates expected to run beside this handle's (tile plan hint)
     int goal_frames = 0;      // goal frames whose tokens / descriptors are cached in rows [0, goal_frames) (vitvs_set_goal_dev)
 };
@@ -508,8 +509,27 @@ void vitvs_destroy(vitvs_handle* h) {
     delete h;
 }
 
+int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src) {
+    if (!h || !src || h == src) return set_err(h, -1, "null argument");
+    const vitvs_config &a = h->cfg, &b = src->cfg;
+    if (h->device != src->device) return set_err(h, -5, "handles of different devices cannot share weights");
+    if (a.img_size != b.img_size || a.patch != b.patch || a.stride != b.stride || a.dim != b.dim || a.heads != b.heads ||
+        a.blocks != b.blocks || a.layerscale != b.layerscale || a.precision != b.precision)
+        return set_err(h, -5, "weights are shared between handles of one network, input geometry and precision");
+    if (!h->have.empty() && !h->borrowed) return set_err(h, -5, "this handle already holds weights of its own");
+    if (src->borrowed) return set_err(h, -5, "share from the handle that owns the weights");
+    if (vitvs_weights_ready(src) != 0) return set_err(h, -4, "the source handle's weights are not fully loaded");
+    h->blk = src->blk;
+    h->pe_w = src->pe_w; h->pe_b = src->pe_b; h->cls = src->cls; h->pos = src->pos;
+    h->have = src->have;
+    h->ready = true;
+    h->borrowed = true;
+    return 0;
+}
+
 int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64_t numel) {
     if (!h || !name || !data) return set_err(h, -1, "null argument");
+    if (h->borrowed) return set_err(h, -5, "this handle borrows its weights (vitvs_share_weights): upload to their owner");
     DeviceScope dev(h);
     const vitvs_config& c = h->cfg;
     const size_t D = c.dim, H4 = h->hidden;

@@ -223,7 +223,12 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
     // keeps a second launch's workgroups off the CU until the first has left; 4-wave workgroups (64-80 KB) let two launches
     // share it: ViT-B/16 224², 3 updates in flight 3113 -> 3392 updates/s, but 2220 -> 2078 on one stream (same box,
     // profiles/r03_notes.md section 5), hence by the caller's hint and not by default.
-    const int kg = (g_updates_in_flight < 2 && wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
+    int kg = (g_updates_in_flight < 2 && wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
+#ifdef VITVS_PLAN_ENV                         // experiment builds only (tools/two_streams.py): plan overrides from the environment
+    if (const char* e = getenv("VITVS_X_BN")) { const int v = atoi(e); if (v && !fixed64 && N % v == 0) bn = v; }
+    if (const char* e = getenv("VITVS_X_KG")) { const int v = atoi(e); if (v) kg = v; }
+    if (kg == 2 && (nk_per_slice < 4 || nk_per_slice % 2)) kg = 1;
+#endif
     return TilePlan{bn, kg};
 }
 
@@ -268,6 +273,9 @@ static int ring_stages(int bn, long wgs) {
 
 // Many-row problems (many frame pairs, 448² / 518² inputs): 128x128 tiles halve the LDS and L2 bytes per MFMA.
 static bool big_problem(int M, int N, int splits) {
+#ifdef VITVS_PLAN_ENV
+    if (const char* e = getenv("VITVS_X_128")) { if (atoi(e) && N % 128 == 0) return true; }
+#endif
     // >= 256 tiles: with 2 workgroups per CU that is one round on every CU or more (measured: 294 tiles -12 %, 176 tiles
     // +37 % against 64x64 tiles)
     return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= 256;
@@ -288,7 +296,10 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiAr
     const int bk = 128 / (int)sizeof(T);
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
-    const int ns = pl.kg == 1 ? ring_stages(pl.bn, (long)((M + 63) / 64) * (N / pl.bn) * splits) : 0;
+    int ns = pl.kg == 1 ? ring_stages(pl.bn, (long)((M + 63) / 64) * (N / pl.bn) * splits) : 0;
+#ifdef VITVS_PLAN_ENV
+    if (const char* e = getenv("VITVS_X_NS")) { if (pl.kg == 1 && atoi(e)) ns = atoi(e); }
+#endif
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
         if (ns == 2) return launch_one<T, 128, 1, Epi, 64, 2>(A, W, M, N, K, epi, stream, splits);
@@ -370,6 +381,9 @@ int splitk_slices(Precision p, int M, int N, int K) {
     // The most K slices that still put at most one workgroup on every CU (each slice >= 4 k-tiles);
     // none if the tiles alone already cover the chip.
     const long tiles = (long)((M + 63) / 64) * (N / 64);
+#ifdef VITVS_PLAN_ENV
+    if (const char* e = getenv("VITVS_X_SPLITS")) { const int v = atoi(e); if (v && K % (v * bk) == 0 && K / v >= 4 * bk) return v; }
+#endif
     int best = 1;
     for (int c : {2, 3, 4, 6, 8}) {
         if ((K % (c * bk)) != 0 || K / c < 4 * bk) continue;
@@ -392,6 +406,9 @@ int launch_linear_partial_classic(Precision p, const void* A, const void* W, flo
     const EpiArgs e{part, nullptr, nullptr, 0};
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
     if (p == PREC_F16) return launch_tiles64<f16, EpiPartial>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
+#ifdef VITVS_PLAN_ENV
+    if (getenv("VITVS_X_PBN")) return launch_tiles<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
+#endif
     return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 

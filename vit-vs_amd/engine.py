@@ -108,6 +108,13 @@ class Engine:
         self._check(self.lib.vitvs_weights_ready(self.handle), "vitvs_weights_ready")
         return self
 
+    def share_weights(self, owner: "Engine") -> "Engine":
+        """Borrow ``owner``'s device weights instead of uploading a copy (``vitvs_share_weights``): same network, input
+        geometry and precision; ``owner`` must stay alive as long as this engine."""
+        self._check(self.lib.vitvs_share_weights(self.handle, owner.handle), "vitvs_share_weights")
+        self._weights_owner = owner                      # keeps the owner (and its device memory) alive
+        return self
+
     # ------------------------------------------------------------------ helpers
     def _frames(self, frames) -> torch.Tensor:
         t = torch.as_tensor(frames)

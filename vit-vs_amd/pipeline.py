@@ -6,8 +6,8 @@ control loops sharing the GPU, or a frame stream handled as a pipeline — overl
 handles on different HIP streams (measured on MI355X, ViT-B/16 224², bf16: 2220 updates/s on one stream, 2830 / 3110 with
 2 / 3 in flight, 3390 with the 4-wave GEMM plan the ``in_flight`` hint selects; profiles/r03_notes.md section 5).
 
-``UpdatePipeline`` is that arrangement: ``depth`` handles (each with its own weights copy and workspaces: one call in
-flight per handle, include/vitvs.h) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
+``UpdatePipeline`` is that arrangement: ``depth`` handles (own workspaces, one call in flight per handle, include/vitvs.h;
+the weights are uploaded once and borrowed by the others, vitvs_share_weights) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
 makes cheap enough (~50 us of host time per update).  Every update is the same computation as ``Engine.compute_velocity_dev``
 — the reference's ``detect_features`` + ``ibvs`` up to the raw twist (vitvs_v2.py:464-523, 588-622) — and its results
 are bit-identical to the one-stream call's with the same plan (tests/test_gpu_pipeline.py).
@@ -32,14 +32,17 @@ class UpdatePipeline:
 
     def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "bf16", depth: int = 3,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
-                 plan_hint: bool = True, stream_priority: int = -1):
+                 plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True):
         if depth < 1:
             raise VitvsError("depth must be >= 1")
         self.depth = int(depth)
         self.engines: List[Engine] = []
         for _ in range(self.depth):
             e = Engine(cfg, params, precision=precision, max_pairs=max_pairs, max_rows=max_rows, device=device)
-            e.load_state_dict(state_dict)
+            if self.engines and share_weights:
+                e.share_weights(self.engines[0])           # one resident copy of the weights for every queue
+            else:
+                e.load_state_dict(state_dict)
             e.set_option("graph_replay", int(graph_replay))
             if plan_hint:
                 e.set_option("in_flight", self.depth)
@@ -58,7 +61,7 @@ class UpdatePipeline:
         self.submitted = 0
 
     def close(self):
-        for e in self.engines:
+        for e in reversed(self.engines):                 # borrowers first, the owner of the weights last
             e.close()
         self.engines = []
 
