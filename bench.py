@@ -522,7 +522,8 @@ def run_rank(args):
         pipe = UpdatePipeline(cfg, params, sd, precision=args.precision, depth=in_flight, max_pairs=B,
                               max_rows=cfg.tokens if dense else None, device=dev,
                               stream_priority=int(os.environ.get("VITVS_PIPE_PRIORITY", "-1")),
-                              share_weights=os.environ.get("VITVS_PIPE_SHARE", "1") == "1")   # (A/B tooling: tools/ab_bench.sh)
+                              share_weights=os.environ.get("VITVS_PIPE_SHARE", "1") == "1",    # (A/B tooling: tools/ab_bench.sh)
+                              plan_hint=os.environ.get("VITVS_PIPE_HINT", "1") == "1")
 
     # per-rank synthetic inputs, resident in HBM.  The headline configuration draws its pairs from the accepted rig
     # seeds (rank r, pair i -> seed index (r * B + i) mod 8), so the 8-GPU run IS configs[3]'s 8-camera rig.

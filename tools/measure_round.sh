@@ -28,6 +28,11 @@ done
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_p8 -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --pairs 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/rocprof_trace_p8.err ) || exit 1
 # ViT-L/14 518² (configs[4]): 2740 rows, 1370-token attention
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_l -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --config vitl14_518 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-plain-chain > /dev/null 2> $GRAFT_REPO_ROOT/$O/rocprof_trace_l.err ) || exit 1
+# several updates in flight: depth sweep of the headline, dispatch rate and per-operator overlap across queues
+for k in 1 2 3 4 5; do python bench.py --in-flight $k --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --no-plain-chain > $O/bench_bf16_in_flight$k.json 2>/dev/null || exit 1; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_bf16_driver_form.json 2>/dev/null || exit 1
+tools/launch_floor queues > $O/launch_floor_queues.txt 2>&1
+tools/op_chain queues > $O/op_chain_queues.txt 2>&1
 python tools/vendor_compare.py > $O/vendor.txt 2> $O/vendor.err
 tools/launch_floor > $O/launch_floor.txt 2>&1
 tools/valu_rate > $O/valu_rate.txt 2>&1
