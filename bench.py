@@ -51,7 +51,7 @@ def parse_args(argv=None):
                     help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent updates in flight per GPU (handles x streams, vit-vs_amd/pipeline.py); 0 = the measured "
-                         "default: 4 up to a thousand rows per layer, 3 beyond; 1 = one stream, as in rounds 1-2")
+                         "default 3; 1 = one stream, as in rounds 1-2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode leg")
     ap.add_argument("--no-plain-chain", action="store_true",
@@ -513,9 +513,10 @@ def run_rank(args):
     # Updates of a throughput run do not depend on each other: `value` is measured with `in_flight` of them enqueued on as
     # many streams through as many handles (vit-vs_amd/pipeline.py); the one-stream figure of the earlier rounds is reported
     # beside it as `sequential`.
-    # default depth (profiles/r03_notes.md section 5): 4 while one update is at most a thousand rows per layer (3328 -> 3431
-    # updates/s from 3 to 4 at one ViT-B/16 pair), 3 beyond (8 pairs 8390, no gain from a fourth; 448² / 518² inputs are flat from 2)
-    in_flight = args.in_flight if args.in_flight > 0 else (4 if 2 * B * cfg.seq <= 1024 else 3)
+    # default depth 3 (profiles/r03_notes.md section 5): the command processor overlaps the launch-to-launch floor of up to
+    # three queues (0.64 us per empty launch overall against 1.62 on one queue) and falls apart with a fourth busy one in the
+    # micro-benchmark (tools/launch_floor queues); in this benchmark a fourth update in flight measured +2 %, a fifth -17 %
+    in_flight = args.in_flight if args.in_flight > 0 else 3
     pipe = None
     if in_flight > 1:
         from vitvs_amd.pipeline import UpdatePipeline
@@ -546,10 +547,9 @@ def run_rank(args):
     v = torch.zeros((B, 6), dtype=torch.float64, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     v_all = torch.zeros((world * B, 6), dtype=torch.float64, device=dev) if multi else None
-    # N > 1: one synchronous v_c all-gather per update (torch.distributed on RCCL).  VITVS_ASYNC_GATHER=1 issues it
-    # asynchronously on RCCL's own stream with alternating buffers (vit-vs_amd/dist.py: VelocityGather) — measured on one
-    # GPU in a world of one rank that is SLOWER (0.577 vs 0.464 ms per update; no gather: 0.449): work of two queues
-    # alternates on this platform instead of overlapping, so the second queue costs more than the wait it removes.
+    # N > 1: one v_c all-gather per update (torch.distributed on RCCL), enqueued behind the update on the update's own stream.
+    # VITVS_ASYNC_GATHER=1 (one update in flight only) issues it asynchronously on RCCL's stream with alternating buffers
+    # (vit-vs_amd/dist.py: VelocityGather) — measured SLOWER on one GPU in a world of one rank (0.577 vs 0.464 ms per update).
     async_gather = (multi and os.environ.get("VITVS_DIST_BACKEND", "nccl") == "nccl"
                     and os.environ.get("VITVS_ASYNC_GATHER") == "1" and pipe is None)
     gather = vdist.VelocityGather(world * B, dev) if async_gather else None
@@ -600,8 +600,8 @@ def run_rank(args):
     sequential = None
     with torch.cuda.stream(stream):
         if pipe is not None:
-            for i in range(in_flight):              # every slot's graph is captured before anything is timed
-                pipe_step(i)
+            for i in range(2 * in_flight):          # set-up, not warm-up: every slot captures its graph (first call) and
+                pipe_step(i)                        # uploads the instantiated graph (first replay) before anything is timed
             pipe_fence()
             elapsed = timed_updates(None, pipe_step, pipe_fence, args.warmup, args.steps, dev)
             last = (pipe.submitted - 1) % in_flight

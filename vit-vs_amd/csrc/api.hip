@@ -261,9 +261,11 @@ struct ChainCtx {
     DescOut desc;
 };
 
-// The forward, operator by operator, on one stream.  (Two chains — the two frames on two streams, or in lockstep on one
-// stream with hipExtAnyOrderLaunch — were measured in round 1: kernels of different queues alternate instead of
-// overlapping on this platform and gfx9 ignores the any-order flag, so the code was removed: profiles/r01_notes.md.)
+// The forward, operator by operator, on one stream.  (The two FRAMES of one update as two chains — on two streams, or in
+// lockstep on one stream with hipExtAnyOrderLaunch — were measured in round 1 and gained nothing: half-size launches cost
+// nearly what full-size ones do, gfx9 ignores the any-order flag, and the kernel-trace timelines that showed the queues
+// taking turns were the profiler's own serialisation (profiles/r03_notes.md section 5).  What does overlap is whole,
+// independent UPDATES on separate handles and queues: include/vitvs.h "several updates in flight", vit-vs_amd/pipeline.py.)
 int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     const vitvs_config& c = h->cfg;
     const int D = c.dim;

@@ -59,9 +59,10 @@ def gather_velocities(v_local: torch.Tensor, n_pairs: int, group=None, out: torc
 class VelocityGather:
     """The per-update ``v_c`` all-gather issued asynchronously (opt-in: ``bench.py`` with VITVS_ASYNC_GATHER=1).
 
-    Measured on one MI355X in a world of one rank: slower than the synchronous gather (0.577 vs 0.464 ms per update),
-    because work of two hardware queues alternates instead of overlapping on this platform; kept for multi-GPU
-    experiments, where the collective's latency is longer.
+    Measured on one MI355X in a world of one rank (round 1): slower than the synchronous gather (0.577 vs 0.464 ms per
+    update) — the extra queue's events cost more than the wait they remove; kept for multi-GPU experiments, where the
+    collective's latency is longer.  With several updates in flight (vit-vs_amd/pipeline.py) each update's gather simply
+    follows it on its own stream and overlaps the other updates.
 
     ``post(v_local)`` issues the collective asynchronously: with RCCL it runs on the communicator's own stream behind an
     event of the caller's stream, so the next update's launches do not wait for it; the previous update's collective is
