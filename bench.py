@@ -206,7 +206,7 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
 
 
 # ----------------------------------------------------------------------------------------------- work model
-def split_k(m, n, k, bk):
+def split_k(m, n, k, bk, in_flight=1):
     """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip (bk = 64 for the 16-bit precisions, 32 for fp32)."""
     if bk == 64 and m >= 1024 and n % 128 == 0:
         t128 = -(-m // 256) * (n // 128)
@@ -223,19 +223,19 @@ def split_k(m, n, k, bk):
     for c in (2, 3, 4, 6, 8):
         if k % (c * bk) == 0 and k // c >= 4 * bk and tiles * c <= 256:
             best = c
-    return best
+    return min(best, 2) if in_flight >= 2 else best     # beside other queues' launches: at most two slices
 
 
-def kernel_work(cfg, n_img, n_pairs, es, binned):
+def kernel_work(cfg, n_img, n_pairs, es, binned, in_flight=1):
     """Algorithmic FLOPs and minimum HBM bytes per LAUNCH of each kernel class."""
     n, t, d, h = cfg.seq, cfg.tokens, cfg.dim, cfg.hidden
     m = n_img * n
     bk = 128 // es
-    s_proj, s_fc2 = split_k(m, d, d, bk), split_k(m, d, h, bk)
+    s_proj, s_fc2 = split_k(m, d, d, bk, in_flight), split_k(m, d, h, bk, in_flight)
     s_avg = (s_proj + s_fc2) / 2
     dp = d * (9 if binned else 1)
     kp = -(-cfg.patch_k // 64) * 64
-    s_pe = split_k(n_img * t, d, kp, bk)
+    s_pe = split_k(n_img * t, d, kp, bk, in_flight)
     return {
         "patchify": (0.0, n_img * cfg.img_size ** 2 * 3 + n_img * t * kp * es),
         # split-K patch embedding, finished (with cls / pos_embed / block 0's norm1) by the "layernorm" class
@@ -612,8 +612,8 @@ def run_rank(args):
                 el_seq = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
                 sequential = dict(metric="servo_updates_per_sec", value=round(B * args.steps / el_seq, 2), unit="updates/s",
                                   steps=args.steps, warmup=args.warmup, ms_per_step=round(el_seq / args.steps * 1e3, 4),
-                                  note="one update in flight: one handle, one stream, plain launches (what `value` was in "
-                                       "rounds 1-2); the per-kernel table and the roofline object are measured in this form")
+                                  note="one update in flight: one handle, one stream, plain launches, the one-stream tile plan "
+                                       "(what `value` was in rounds 1-2)")
         else:
             elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
         if multi:
@@ -642,19 +642,24 @@ def run_rank(args):
             torch.cuda.synchronize(dev)
             lat.append(time.perf_counter() - t1)
 
-        # instrumented pass: HIP event pairs around every launch, on the launch stream
-        eng.timing_enable(True)
+        # instrumented pass: HIP event pairs around every launch, on the launch stream, one update at a time (kernels of
+        # several queues share the chip: a kernel's own duration is only defined while it runs alone).  With several updates
+        # in flight it runs on one of the pipeline's handles, i.e. the kernels and the tile plan `value` was measured with.
+        eng_prof = pipe.engines[0] if pipe is not None else eng
+        prof_step = make_step(eng_prof)
+        eng.lib.vitvs_op_plan_in_flight(in_flight)      # the operator hooks below (tile symbol, plain chain) plan alike
+        eng_prof.timing_enable(True)
         n_prof = min(args.steps, 50)
         for i in range(n_prof):
-            step(args.warmup + i)
+            prof_step(args.warmup + i)
         if gather is not None:
             gather.finish()
-        prof = eng.timing_collect()
-        eng.timing_enable(False)
+        prof = eng_prof.timing_collect()
+        eng_prof.timing_enable(False)
         plain = None
         if rank == 0 and world == 1 and not args.no_plain_chain:   # single-process extra; ranks stay in lock step at N > 1
             m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
-            plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_), dev)
+            plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_, in_flight), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
         parity = None
@@ -668,7 +673,7 @@ def run_rank(args):
             el32 = timed_updates(eng32, make_step(eng32), fence, s_warm, s_steps, dev)
             secondary = dict(dtype="fp32", metric="servo_updates_per_sec", value=round(B * s_steps / el32, 2), unit="updates/s",
                              steps=s_steps, warmup=s_warm, ms_per_step=round(el32 / s_steps * 1e3, 4),
-                             note="parity mode: v_c <= 1e-4 and bit-exact arg-max are asserted in this mode "
+                             note="one update in flight.  Parity mode: v_c <= 1e-4 and bit-exact arg-max are asserted in this mode "
                                   "(tests/test_gpu_path.py); its MFMA ceiling is 157 TFLOP/s -> ~2.2 k updates/s")
             if not args.no_cpu_baseline:
                 secondary["parity"] = parity_block(eng32, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K,
@@ -684,13 +689,13 @@ def run_rank(args):
             elc = timed_updates(eng, make_step(eng, "cached"), fence, c_warm, c_steps, dev)
             goal_cached = dict(metric="servo_updates_per_sec", value=round(B * c_steps / elc, 2), unit="updates/s", steps=c_steps,
                                warmup=c_warm, ms_per_step=round(elc / c_steps * 1e3, 4), dtype=args.precision,
-                               note="goal tokens cached (vitvs_set_goal_dev): only the current frame is forwarded; the "
+                               note="one update in flight, goal tokens cached (vitvs_set_goal_dev): only the current frame is forwarded; the "
                                     "reference recomputes I_des every update, and so does `value`")
 
     updates = world * B * args.steps
     value = updates / elapsed
     es = 4 if args.precision == "fp32" else 2
-    work = kernel_work(cfg, 2 * B, B, es, binned)
+    work = kernel_work(cfg, 2 * B, B, es, binned, in_flight)
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
@@ -728,7 +733,7 @@ def run_rank(args):
         return f"linear_kernel<{prec_tag},{tile[0]},{tile[1]},{tile[2]}>:" + ("EpiPartial" if partial else "EpiStore")
     m_all = 2 * B * cfg.seq
     bk_es = 128 // es
-    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es), True),
+    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es, in_flight), True),
               "residual_ln": f"residual_ln_kernel<{prec_tag}>",
               "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, False),
               "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, False),

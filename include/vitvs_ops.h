@@ -53,6 +53,9 @@ VITVS_API int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out
  *   x[M][D] (fp32) += ls[D] * (sum_z part[z] + bias)  (slices summed in index order); then, if gamma != NULL,
  *   out[M][D] = LayerNorm(x) * gamma + beta in `precision` (out may be NULL when gamma is NULL). */
 VITVS_API int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K);
+/* The plan hint a handle carries as its "in_flight" option (vitvs.h), for the pointer-only hooks of this header: the calling
+ * thread's later vitvs_op_* calls plan as if n updates were in flight (n >= 1; n < 1 only reads).  Returns the previous value. */
+VITVS_API int vitvs_op_plan_in_flight(int32_t n);
 /* the tile the library launches for a linear layer: tile[0..2] = rows, columns, k-groups (k-groups 0: the 256-row kernels of
  * gemm_big.hip); slices = 0: vitvs_op_linear, > 0: vitvs_op_linear_partial with that many K slices.  No device work. */
 VITVS_API int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int32_t slices, int32_t* tile);

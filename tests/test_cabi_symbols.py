@@ -77,6 +77,18 @@ def test_bench_split_k_mirror_matches_the_library_plan():
         for m in (197, 394, 788, 1576, 3152, 970, 2740, 6274):
             for n, k in ((768, 768), (768, 3072), (384, 384), (384, 1536), (1024, 1024), (1024, 4096), (768, 640), (768, 192)):
                 assert bench.split_k(m, n, k, bk) == lib.vitvs_op_splitk_slices(prec, m, n, k), (prec, m, n, k)
+    # ... and under the plan hint of a handle whose updates run beside others (vitvs_set_option "in_flight")
+    assert lib.vitvs_op_plan_in_flight(3) == 1
+    try:
+        for m in (197, 394, 788, 3152):
+            for n, k in ((768, 768), (768, 3072), (384, 1536)):
+                assert bench.split_k(m, n, k, 64, 3) == lib.vitvs_op_splitk_slices(_lib.BF16, m, n, k), (m, n, k)
+        t = (ctypes.c_int32 * 3)()
+        assert lib.vitvs_op_linear_tile(_lib.BF16, 394, 2304, 768, 0, t) == 0 and list(t) == [64, 64, 1]   # 4-wave workgroups
+    finally:
+        assert lib.vitvs_op_plan_in_flight(1) == 3
+    t = (ctypes.c_int32 * 3)()
+    assert lib.vitvs_op_linear_tile(_lib.BF16, 394, 2304, 768, 0, t) == 0 and list(t) == [64, 64, 2]
 
 
 def test_linear_tile_plan_of_the_library():

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "vitvs_op_attention": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "vitvs_op_attention_q": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_splitk_slices": (_I, [_I, _I, _I, _I]),
+    "vitvs_op_plan_in_flight": (_I, [_I]),
     "vitvs_op_linear_tile": (_I, [_I, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_partial": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_residual_ln": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),

@@ -135,7 +135,8 @@ struct DeviceScope {
         const int want = h ? h->device : prev;
         if (want != prev) switched = hipSetDevice(want) == hipSuccess;
         g_current_device = switched ? want : prev;
-        g_updates_in_flight = h ? h->in_flight : 1;   // the tile plan of this handle's launches (kernels.h)
+        if (h) g_updates_in_flight = h->in_flight;    // the tile plan of this handle's launches (kernels.h); the pointer-only
+                                                      // operator hooks keep the thread's own hint (vitvs_op_plan_in_flight)
     }
     ~DeviceScope() {
         if (switched) { (void)hipSetDevice(prev); g_current_device = prev; }
@@ -1131,6 +1132,11 @@ int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int
     const int rc = linear_tile_plan(to_prec(precision), M, N, K, slices > 0 ? slices : 1, slices > 0, t);
     tile[0] = t[0]; tile[1] = t[1]; tile[2] = t[2];
     return rc;
+}
+int vitvs_op_plan_in_flight(int32_t n) {
+    const int prev = g_updates_in_flight;
+    if (n >= 1) g_updates_in_flight = n;
+    return prev;
 }
 int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
     return splitk_slices(to_prec(precision), M, N, K);
