@@ -122,6 +122,11 @@ struct EpiPartial {
 __device__ unsigned long long* g_gemm_probe;
 #endif
 
+#ifdef VITVS_DBG_NO_WT        // experiment builds: plain stores instead of write-through ones in the 64-row epilogues
+#define VITVS_EPI_WT(BM) false
+#else
+#define VITVS_EPI_WT(BM) ((BM) < 128)
+#endif
 template <typename T, int BM, int BN, int KG, class Epi, int NS = 0>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
@@ -139,7 +144,16 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned pk = (unsigned)ks_i0;
     const int kslice = (int)(pk >> 24) * 32;
-    const int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
+    int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
+    if (pk & (1u << 16)) {
+        // XCD map of the two-slice partial-sum launches (launch_one): a 1-D grid whose workgroup L runs on XCD L % 8; XCD x
+        // takes K slice x / 4 and the column tiles of class x % 4, all row tiles of them.  A weight tile is then fetched by
+        // ONE private L2 (every row tile that needs it is there) and an activation slice by four instead of eight.
+        const int L = blockIdx.x, x = L & 7, r = L >> 3, ncq = (N / BN) >> 2;
+        ty = r / ncq;
+        tx = (x & 3) + 4 * (r - ty * ncq);
+        tz = x >> 2;
+    }
     epi.set_slice(tz);
     const int m0 = ty * BM, n0 = tx * BN;
     f32x4 acc[Tile::NT][Tile::MT];
@@ -164,9 +178,9 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
             if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
 #ifdef VITVS_DBG_NO_EPI
-            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi.template store<(BM < 128)>(m, n, acc[ni][mi], col[ni]);
+            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi.template store<VITVS_EPI_WT(BM)>(m, n, acc[ni][mi], col[ni]);
 #else
-            if (m < M && n < N) epi.template store<(BM < 128)>(m, n, acc[ni][mi], col[ni]);   // 64-row tiles: one-wave launches
+            if (m < M && n < N) epi.template store<VITVS_EPI_WT(BM)>(m, n, acc[ni][mi], col[ni]);   // 64-row tiles: one-wave launches
 #endif
         }
     }
@@ -239,6 +253,19 @@ struct EpiArgs {   // host image of the flat epilogue arguments
     int i0;
 };
 
+// The XCD map (linear_kernel) is for the partial-sum launches only (their i0 field is unused, bit 16 of the packed argument is free)
+template <class Epi> constexpr bool xcd_mapped() { return false; }
+template <> constexpr bool xcd_mapped<EpiPartial>() { return true; }
+static bool want_xcd_map() {
+#ifdef VITVS_PLAN_ENV
+    if (const char* e = getenv("VITVS_X_XCDMAP")) return atoi(e) != 0;
+#endif
+    // Beside other queues' launches the narrow layers are bound by what their private L2s fetch, not by latency (fc2 at three
+    // queues 4.48 -> 3.67 us per launch, 3932 -> 4072 updates/s); alone, XCD balance comes first (round 1: the map lost).
+    // (A column-class map for the one-slice launches — qkv's 36 column tiles over 8 XCDs — lost: 3.13 -> 3.37 us.)
+    return g_updates_in_flight >= 2;
+}
+
 template <typename T, int BN, int KG, class Epi, int BM = 64, int NS = 0>
 static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs& e, hipStream_t stream, int splits) {
     using Tile = GemmTile<BM, BN, KG, NS>;
@@ -247,8 +274,13 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
     const int kslice = K / splits;
     if (kslice % 32 != 0 || kslice / 32 > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff) return -2;
+    unsigned xcd_map = 0;
+    if (xcd_mapped<Epi>() && splits == 2 && (N / BN) % 4 == 0 && want_xcd_map()) {
+        grid = dim3(grid.x * grid.y * 2, 1, 1);
+        xcd_map = 1u << 16;
+    }
     launch(linear_kernel<T, BM, BN, KG, Epi, NS>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1,
-           M, N, K, (int)(((unsigned)(kslice / 32) << 24) | (unsigned)e.i0));
+           M, N, K, (int)(((unsigned)(kslice / 32) << 24) | xcd_map | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
