@@ -100,6 +100,27 @@ def test_in_flight_plan_meets_the_reference_fixture_in_fp32(key):
     eng.close()
 
 
+def test_staged_inputs_replay_one_graph_per_slot_whatever_buffers_the_caller_brings():
+    """Frames arriving in a fresh device buffer every update (a camera driver's ring): with stage_inputs the slot copies them into
+    buffers of its own, every call of a slot replays the slot's one captured graph, and the results are those of the direct call."""
+    dev = torch.device("cuda", 0)
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    _, _, des, cur, Z, K = _inputs(cfg, params, synth.RIG8_FRAME_SEEDS[:3], dev)
+    orders = _orders(cfg, 9, dev)
+    ref = UpdatePipeline(cfg, params, sd, precision="bf16", depth=2)
+    want = [ref.result(ref.submit(cur[i % 3], des[i % 3], Z, K, _lib.SELECT_ORDER, orders[i]))[0].cpu().numpy() for i in range(9)]
+    ref.close()
+    pipe = UpdatePipeline(cfg, params, sd, precision="bf16", depth=2, stage_inputs=True)
+    for i in range(9):
+        fresh = [t.clone() for t in (cur[i % 3], des[i % 3], Z, K, orders[i])]          # new addresses every update
+        got = pipe.result(pipe.submit(fresh[0], fresh[1], fresh[2], fresh[3], _lib.SELECT_ORDER, fresh[4]))[0].cpu().numpy()
+        assert np.array_equal(got, want[i]), f"update {i}"
+    assert all(set(st) == {"cur", "des", "Z", "K", "sel"} for st in pipe._staged)
+    pipe.close()
+
+
 def test_tickets_options_and_cached_goal():
     dev = torch.device("cuda", 0)
     blob = load_golden("e2e_vitb16_224.npz")                    # an accepted pair: arg-max margins above the fp32 noise

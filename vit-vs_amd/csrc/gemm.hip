@@ -46,18 +46,33 @@ struct EpiStore {
         return EpiStore{(T*)out, c0, N, i0};
     }
     __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
-    template <bool WT>
-    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
+    // staged epilogue (linear_kernel): the tile leaves through an LDS image as whole rows
+    using Out = T;
+    static constexpr bool STAGED = true;
+    __device__ __forceinline__ f32x4 value(f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
+        return v;
+    }
+    __device__ __forceinline__ T* row(int m) const { return out + (size_t)m * ldo; }
+    template <bool WT>
+    __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+#ifndef VITVS_DBG_NO_GELU       // experiment builds: what the activation's arithmetic costs (results are wrong without it)
+        if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
+        }
+#endif
         store4<T, WT>(out + (size_t)m * ldo + n, v);
     }
 };
 
 struct EpiResidual {
+    static constexpr bool STAGED = false;
     float* x;
     const float* bias;
     const float* ls;  // may be null
@@ -82,6 +97,7 @@ struct EpiResidual {
 };
 
 struct EpiPatch {
+    static constexpr bool STAGED = false;
     float* x;
     const float* bias;
     const float* pos;
@@ -111,6 +127,10 @@ struct EpiPartial {
     }
     __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void set_slice(int z) { part += (size_t)z * M * N; }
+    using Out = float;
+    static constexpr bool STAGED = true;
+    __device__ __forceinline__ f32x4 value(f32x4 v, float4) const { return v; }
+    __device__ __forceinline__ float* row(int m) const { return part + (size_t)m * N; }
     template <bool WT>
     __device__ __forceinline__ void store(int m, int n, f32x4 v, float4) const {
         store4<float, WT>(part + (size_t)m * N + n, v);
@@ -170,6 +190,43 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
     ts[4] = __builtin_readcyclecounter();
 #endif
+    if constexpr (BM == 64 && Epi::STAGED) {
+        if (pk & (1u << 18)) {
+            // Staged epilogue: a lane of the MFMA layout owns 4 consecutive columns of one row, so a wave's store instruction
+            // writes 16 rows x 32 bytes (16-bit output) — four partial lines per row over the tile.  Here the tile goes through an
+            // LDS image (the ring is free: every wave is past its last k-tile) and leaves as 16-byte pieces of whole rows:
+            // consecutive lanes write consecutive bytes, whole 128-byte lines.
+            using Out = typename Epi::Out;
+            constexpr int ROWB = BN * (int)sizeof(Out), PITCH = ROWB + 16, CH = ROWB / 16;
+            // one k-group: the barrier ends the last k-tile's reads.  Two k-groups: the ring has been free since the barrier of
+            // the accumulator swap (gemm_mainloop) unless the swap area itself lives in the ring; each group stages the tiles it owns.
+            if constexpr (KG == 1 || Tile::SWAP_ALIAS) __syncthreads();
+#pragma unroll
+            for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < Tile::MT; ++mi) {
+                    if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
+                    const f32x4 v = epi.value(acc[ni][mi], col[ni]);
+                    unsigned char* dst = smem + (wm * Tile::WM + mi * 16 + (lane & 15)) * PITCH +
+                                         (wn * Tile::WN + ni * 16 + 4 * (lane >> 4)) * (int)sizeof(Out);
+                    if constexpr (sizeof(Out) == 4) *reinterpret_cast<f32x4*>(dst) = v;
+                    else {
+                        const typename Vec16<Out>::x4 h = {(Out)v[0], (Out)v[1], (Out)v[2], (Out)v[3]};
+                        *reinterpret_cast<typename Vec16<Out>::x4*>(dst) = h;
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int idx = threadIdx.x; idx < BM * CH; idx += 256 * KG) {
+                const int r = idx / CH, ch = idx - r * CH;
+                if (m0 + r < M) {
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * PITCH + ch * 16);
+                    store_out16<true>(reinterpret_cast<unsigned char*>(epi.row(m0 + r) + n0) + ch * 16, d);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) {
         const int n = n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
@@ -266,6 +323,16 @@ static bool want_xcd_map() {
     return g_updates_in_flight >= 2;
 }
 
+static bool want_staged_epilogue(int kg) {
+#ifdef VITVS_PLAN_ENV
+    if (const char* e = getenv(kg == 2 ? "VITVS_X_STAGED2" : "VITVS_X_STAGED")) return atoi(e) != 0;
+#endif
+    // 4-wave workgroups: measured faster alone and side by side (qkv 6.00 -> 5.11 us alone, 3.07 -> 2.81 at three queues; fc1
+    // 8.62 -> 7.16, 3.99 -> 3.39; 2 pairs +3 % on one stream and +10 % with three updates in flight; never slower)
+    // 8-wave workgroups (two k-groups, the one-stream plan): +1.4 % updates/s on one stream (2202 -> 2233, three interleaved rounds)
+    return true;
+}
+
 template <typename T, int BN, int KG, class Epi, int BM = 64, int NS = 0>
 static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs& e, hipStream_t stream, int splits) {
     using Tile = GemmTile<BM, BN, KG, NS>;
@@ -279,6 +346,7 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
         grid = dim3(grid.x * grid.y * 2, 1, 1);
         xcd_map = 1u << 16;
     }
+    if (BM == 64 && want_staged_epilogue(KG)) xcd_map |= 1u << 18;
     launch(linear_kernel<T, BM, BN, KG, Epi, NS>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1,
            M, N, K, (int)(((unsigned)(kslice / 32) << 24) | xcd_map | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;

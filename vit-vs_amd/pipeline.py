@@ -32,7 +32,8 @@ class UpdatePipeline:
 
     def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "bf16", depth: int = 3,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
-                 plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True):
+                 plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True,
+                 stage_inputs: bool = False):
         if depth < 1:
             raise VitvsError("depth must be >= 1")
         self.depth = int(depth)
@@ -59,6 +60,21 @@ class UpdatePipeline:
         self.v = [torch.zeros((n, 6), dtype=torch.float64, device=self.device) for _ in range(self.depth)]
         self.status = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
         self.submitted = 0
+        # A replayed graph is keyed on the call's argument pointers (include/vitvs.h): a caller whose frames arrive in a new
+        # buffer every update would re-capture every time.  With stage_inputs the slot owns its input buffers and `submit`
+        # copies into them on the slot's stream (five small device-to-device copies), so every call of a slot replays.
+        self.stage_inputs = bool(stage_inputs)
+        self._staged = [dict() for _ in range(self.depth)]
+
+    def _stable(self, k: int, name: str, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        if t is None or not self.stage_inputs:
+            return t
+        buf = self._staged[k].get(name)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty_like(t)
+            self._staged[k][name] = buf
+        buf.copy_(t, non_blocking=True)
+        return buf
 
     def close(self):
         for e in reversed(self.engines):                 # borrowers first, the owner of the weights last
@@ -76,6 +92,8 @@ class UpdatePipeline:
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
+            I_cur, I_des, Z, K = (self._stable(k, n, t) for n, t in (("cur", I_cur), ("des", I_des), ("Z", Z), ("K", K)))
+            selection, n_selected = self._stable(k, "sel", selection), self._stable(k, "nsel", n_selected)
             self.engines[k].compute_velocity_dev(I_cur, I_des, Z, K, mode, selection, n_selected, des_shared,
                                                  self.v[k], self.status[k], num_pairs)
             self.done[k].record(st)
