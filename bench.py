@@ -600,6 +600,17 @@ def run_rank(args):
     sequential = None
     with torch.cuda.stream(stream):
         if pipe is not None:
+            # first the same updates one at a time on one stream — rounds 1-2's `value`, same W and K, with its per-update
+            # all-gather at N > 1 — then the pipelined leg that `value` reports (every rank runs both, in this order)
+            el_seq = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
+            if multi:
+                ts = torch.tensor([el_seq], dtype=torch.float64, device=dev)
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                el_seq = float(ts.item())
+            sequential = dict(metric="servo_updates_per_sec", value=round(world * B * args.steps / el_seq, 2), unit="updates/s",
+                              steps=args.steps, warmup=args.warmup, ms_per_step=round(el_seq / args.steps * 1e3, 4),
+                              note="one update in flight per GPU: one handle, one stream, plain launches, the one-stream tile "
+                                   "plan (what `value` was in rounds 1-2); measured before the pipelined leg")
             for i in range(2 * in_flight):          # set-up, not warm-up: every slot captures its graph (first call) and
                 pipe_step(i)                        # uploads the instantiated graph (first replay) before anything is timed
             pipe_fence()
@@ -608,12 +619,6 @@ def run_rank(args):
             v.copy_(pipe.v[last]); status.copy_(pipe.status[last])
             if multi:
                 v_all.copy_(v_all_slots[last])
-            if world == 1:                          # the same updates one at a time on one stream (rounds 1-2's `value`)
-                el_seq = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
-                sequential = dict(metric="servo_updates_per_sec", value=round(B * args.steps / el_seq, 2), unit="updates/s",
-                                  steps=args.steps, warmup=args.warmup, ms_per_step=round(el_seq / args.steps * 1e3, 4),
-                                  note="one update in flight: one handle, one stream, plain launches, the one-stream tile plan "
-                                       "(what `value` was in rounds 1-2)")
         else:
             elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
         if multi:
