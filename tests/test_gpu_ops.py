@@ -66,6 +66,71 @@ def test_linear(lib, name, prec, dtype, tol, M, N, K, gelu):
     assert _rel(out.cpu(), ref) <= tol
 
 
+@pytest.fixture
+def in_flight_plan(lib):
+    """The plan a handle with the "in_flight" option uses (vitvs_op_plan_in_flight): 4-wave workgroups, at most two K slices, the
+    XCD-mapped grid of the two-slice partial-sum launches."""
+    prev = lib.vitvs_op_plan_in_flight(3)
+    yield
+    lib.vitvs_op_plan_in_flight(prev)
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,N,K,gelu", [(394, 2304, 768, 0), (394, 3072, 768, 1), (197, 1152, 384, 0), (61, 768, 768, 1),
+                                        (394, 4096, 1024, 1)])
+def test_linear_under_the_in_flight_plan(lib, in_flight_plan, name, prec, dtype, tol, M, N, K, gelu):
+    """One-round launches on 4-wave workgroups (64 x 64, 64 x 96, 64 x 128 column tiles), whole-row epilogue, ragged last row tile."""
+    t = (C.c_int32 * 3)()
+    assert lib.vitvs_op_linear_tile(prec, M, N, K, 0, t) == 0 and t[0] == 64 and t[2] == 1
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((N, K), g, K ** -0.5).to(dtype)
+    bias = _mk((N,), g, 0.1)
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    guard = 3                                            # rows behind the matrix must stay untouched by the row stores
+    out = torch.full((M + guard, N), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_linear(prec, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(out), M, N, K, gelu, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all()
+    assert _rel(out[:M].cpu(), ref) <= tol
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("M,D,K", [(394, 768, 768), (394, 768, 3072), (197, 1024, 4096), (61, 768, 3072), (394, 384, 1536)])
+def test_split_k_pair_under_the_in_flight_plan(lib, in_flight_plan, name, prec, dtype, tol, M, D, K):
+    """Two K slices on the XCD-mapped 1-D grid (D / 64 column tiles a multiple of 4; 384 / 64 = 6 keeps the plain grid), summed by
+    residual_ln: equal to the reference, and each slice holds the sum over ITS half of K whichever workgroup computed it — with
+    the map and without."""
+    slices = lib.vitvs_op_splitk_slices(prec, M, D, K)
+    assert slices == 2
+    g = torch.Generator().manual_seed(M + D + K)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((D, K), g, K ** -0.5).to(dtype)
+    bias = _mk((D,), g, 0.1)
+    x0 = _mk((M, D), g)
+    x_ref = x0.double() + A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    x = x0.clone().cuda()
+    part = torch.full((slices, M, D), float("nan"), dtype=torch.float32, device="cuda")
+    assert lib.vitvs_op_linear_partial(prec, _p(Ad), _p(Wd), _p(part), M, D, K, slices, _stream()) == 0
+    assert lib.vitvs_op_residual_ln(prec, _p(x), _p(part), slices, _p(bd), None, None, None, None, M, D, 1e-6, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    assert _rel(x.cpu(), x_ref) <= (tol if prec == _lib.F32 else 2e-6 + 1e-3)
+    # the same two slices without the hint (plain 3-D grid, the 8-wave plan where it applies)
+    lib.vitvs_op_plan_in_flight(1)
+    part1 = torch.full((slices, M, D), float("nan"), dtype=torch.float32, device="cuda")
+    assert lib.vitvs_op_linear_partial(prec, _p(Ad), _p(Wd), _p(part1), M, D, K, slices, _stream()) == 0
+    torch.cuda.synchronize()
+    lib.vitvs_op_plan_in_flight(3)
+    ref_slices = torch.stack([A[:, z * (K // 2):(z + 1) * (K // 2)].double() @ W[:, z * (K // 2):(z + 1) * (K // 2)].double().t()
+                              for z in range(2)])
+    for got in (part, part1):                            # each slice holds ITS half of K, whichever workgroup computed it
+        assert _rel(got.cpu(), ref_slices) <= (tol if prec == _lib.F32 else 1e-3)
+
+
 @pytest.mark.parametrize("name,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("M,N,K,use_ls", [(394, 768, 768, False), (394, 768, 3072, True), (130, 384, 1536, True),
                                           # 300 / 600 workgroups of 64 x 64: the 3- and the 2-stage ring (ring_stages, gemm.hip);
