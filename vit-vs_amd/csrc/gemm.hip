@@ -483,7 +483,6 @@ int splitk_slices(Precision p, int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * (N / 64);
 #ifdef VITVS_PLAN_ENV
     if (const char* e = getenv("VITVS_X_SPLITS")) { const int v = atoi(e); if (v && K % (v * bk) == 0 && K / v >= 4 * bk) return v; }
-    if (const char* e = getenv("VITVS_X_SPLITS_SHORTK")) { const int v = atoi(e); if (v && K <= 1024 && K % (v * bk) == 0 && K / v >= 4 * bk) return v; }
 #endif
     int best = 1;
     for (int c : {2, 3, 4, 6, 8}) {
