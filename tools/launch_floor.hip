@@ -143,6 +143,9 @@ static void run_queues(const char* name, int reps, int k, dim3 grid, dim3 block,
                        int copy_n4 = 0, int lds = 0) {
     int lo = 0, hi = 0;
     CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (const char* e = getenv("LF_PRIO")) hi = atoi(e);      // LF_PRIO=0: default-class streams; -1: what torch calls high priority
+    static bool said = false;
+    if (!said) { printf("stream priority range: least %d, greatest %d; using %d\n", lo, hi, hi); said = true; }
     std::vector<hipStream_t> st(k);
     std::vector<hipGraphExec_t> ge(k);
     for (int q = 0; q < k; ++q) {
@@ -182,6 +185,12 @@ static void run_queues(const char* name, int reps, int k, dim3 grid, dim3 block,
 int main(int argc, char** argv) {
     if (argc > 1 && argv[1][0] == 'q') {          // launch_floor queues
         float* buf; CHECK(hipMalloc(&buf, 4096));
+        const int kmax = getenv("LF_KMAX") ? atoi(getenv("LF_KMAX")) : 4;
+        if (getenv("LF_SHORT")) {                 // only the two informative rows, up to LF_KMAX queues
+            for (int k = 1; k <= kmax; ++k) run_queues("empty 252 x 256", 400, k, dim3(252), dim3(256), 0, buf);
+            for (int k = 1; k <= kmax; ++k) run_queues("sleep 3 us 252 x 256", 400, k, dim3(252), dim3(256), 300, buf);
+            return 0;
+        }
         for (int k = 1; k <= 4; ++k) run_queues("empty 256 x 64", 400, k, dim3(256), dim3(64), 0, buf);
         for (int k = 1; k <= 4; ++k) run_queues("empty 252 x 256", 400, k, dim3(252), dim3(256), 0, buf);
         for (int k = 1; k <= 4; ++k) run_queues("sleep 3 us 252 x 256", 400, k, dim3(252), dim3(256), 300, buf);
