@@ -5,18 +5,24 @@ One "step" = one compute_velocity update per GPU: both frames forwarded through 
 recomputed, as the reference does), dense cosine correspondence, mutual-NN filter, 24 features drawn
 in a fresh random visiting order, interaction matrix, pseudo-inverse -> v_c.  Inputs (frames, depth,
 intrinsics, weights, one visiting order per update) are resident in HBM before the timed region; each step is
-enqueued without host synchronisation (86 stream launches), and with N > 1
+enqueued without host synchronisation (86 launches), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--pairs B] [--config KEY]
+The steps of a throughput run do not depend on each other: `value` is measured with `--in-flight` (default 3) of them
+enqueued at a time, each through its own handle on its own high-priority stream (vit-vs_amd/pipeline.py: one copy of the
+weights, graph replay per slot, the in-flight tile plan); W warm-up steps, then exactly K timed steps between barriers and
+device synchronisations, as for one stream.  The line's `sequential` object is the same W + K steps with ONE update in flight
+(one handle, one stream, plain launches) — what `value` was in rounds 1-2 — measured first, on every rank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--pairs B] [--config KEY] [--in-flight D]
 
 `--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts the N ranks itself — one process
 per GPU, before this process touches a GPU — and relays rank 0's line; it fails if fewer than N devices are visible.
 Under `torch.distributed.run` (WORLD_SIZE set) each process is one rank, as the driver launches it.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel symbol with the largest share of the step, timed with
-HIP event pairs on the launch stream in a second, instrumented pass over the same steps (`value` comes from the
-un-instrumented pass).  `parity` compares the benchmarked update with the CPU oracle under the same visiting order;
+HIP event pairs on the launch stream in a second, instrumented pass over the same steps, one update at a time on one of the
+pipeline's handles (the kernels and the tile plan of `value`'s pass; `value` itself comes from the un-instrumented pass).  `parity` compares the benchmarked update with the CPU oracle under the same visiting order;
 `secondary` is the fp32 parity mode measured in the same process; `cpu_baseline` is the CPU oracle (PyTorch-CPU fp32
 forward + the reference's correspondence/control-law arithmetic) timed on this host at N = 1.
 """
