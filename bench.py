@@ -676,7 +676,8 @@ def run_rank(args):
         parity = None
         secondary = None
         if world == 1 and rank == 0 and not args.no_cpu_baseline and not dense:
-            parity = parity_block(eng, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K, orders[0, 0], _lib)
+            # (the handle and tile plan `value` was measured with: a pipeline slot when several updates are in flight)
+            parity = parity_block(eng_prof, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K, orders[0, 0], _lib)
         if world == 1 and rank == 0 and not args.no_secondary and args.precision != "fp32" and not dense:
             # the parity mode (fp32 operands on the exact-fp32 MFMA) in the same process, same inputs and orders
             eng32 = Engine(cfg, params, precision="fp32", max_pairs=B).load_state_dict(sd)
