@@ -74,7 +74,8 @@ class UpdatePipeline:
             buf = torch.empty_like(t)
             self._staged[k][name] = buf
         buf.copy_(t, non_blocking=True)
-        return buf
+        t.record_stream(torch.cuda.current_stream(self.device))   # the caller may drop `t` at once: its memory is not reused
+        return buf                                                # before this (the slot's) stream has copied it
 
     def close(self):
         for e in reversed(self.engines):                 # borrowers first, the owner of the weights last
@@ -86,7 +87,8 @@ class UpdatePipeline:
                mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
                n_selected: Optional[torch.Tensor] = None, des_shared: bool = False, num_pairs: int = 0) -> int:
         """Arguments as ``Engine.compute_velocity_dev`` (device tensors).  The slot's stream first waits for the caller's
-        current stream, so inputs produced there are complete; nothing synchronises the host."""
+        current stream, so inputs produced there are complete; nothing synchronises the host.  Without ``stage_inputs`` the
+        update reads the caller's tensors in place: keep them alive and unchanged until the ticket has completed (``result``)."""
         t = self.submitted
         k = t % self.depth
         st = self.streams[k]
