@@ -46,7 +46,8 @@ static void run(const char* name, hipStream_t st, int reps, const std::function<
 struct Acts { void *xn, *qkv, *attn, *hid; float *x, *part; };
 static int queues_mode(int prec) {
     const size_t es = prec == VITVS_F32 ? 4 : 2;
-    const int M = 394, D = 768, H = 12, N = 197, hidden = 3072, reps = 240;
+    const int n_img = getenv("OPC_IMAGES") ? atoi(getenv("OPC_IMAGES")) : 2;   // OPC_IMAGES=1: one frame per chain (197 rows)
+    const int N = 197, M = n_img * N, D = 768, H = 12, hidden = 3072, reps = 240;
     int lo = 0, hi = 0;
     CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     hipStream_t st[3];
@@ -68,14 +69,14 @@ static int queues_mode(int prec) {
     struct Op { const char* name; int launches; std::function<int(int, int)> f; };   // f(queue, i)
     std::vector<Op> ops = {
         {"qkv   linear 394x2304x768", 1, [&](int q, int i) { return vitvs_op_linear(prec, a[q].xn, wqkv[i % 12], bias, a[q].qkv, M, 3 * D, D, 0, st[q]); }},
-        {"attention 2 x 12 heads x 197", 1, [&](int q, int) { return vitvs_op_attention(prec, a[q].qkv, a[q].attn, 2, N, H, st[q]); }},
+        {"attention 2 x 12 heads x 197", 1, [&](int q, int) { return vitvs_op_attention(prec, a[q].qkv, a[q].attn, n_img, N, H, st[q]); }},
         {"proj  partial 394x768x768", 1, [&](int q, int i) { return vitvs_op_linear_partial(prec, a[q].attn, wproj[i % 12], a[q].part, M, D, D, s_proj, st[q]); }},
         {"residual_ln (3 slices) + LayerNorm", 1, [&](int q, int) { return vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_fc2, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]); }},
         {"fc1   linear+GELU 394x3072x768", 1, [&](int q, int i) { return vitvs_op_linear(prec, a[q].xn, wfc1[i % 12], bias, a[q].hid, M, hidden, D, 1, st[q]); }},
         {"fc2   partial 394x768x3072", 1, [&](int q, int i) { return vitvs_op_linear_partial(prec, a[q].hid, wfc2[i % 12], a[q].part, M, D, hidden, s_fc2, st[q]); }},
         {"block (7 launches)", 7, [&](int q, int i) {
             int rc = vitvs_op_linear(prec, a[q].xn, wqkv[i % 12], bias, a[q].qkv, M, 3 * D, D, 0, st[q]);
-            rc |= vitvs_op_attention(prec, a[q].qkv, a[q].attn, 2, N, H, st[q]);
+            rc |= vitvs_op_attention(prec, a[q].qkv, a[q].attn, n_img, N, H, st[q]);
             rc |= vitvs_op_linear_partial(prec, a[q].attn, wproj[i % 12], a[q].part, M, D, D, s_proj, st[q]);
             rc |= vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_proj, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]);
             rc |= vitvs_op_linear(prec, a[q].xn, wfc1[i % 12], bias, a[q].hid, M, hidden, D, 1, st[q]);
@@ -83,6 +84,7 @@ static int queues_mode(int prec) {
             rc |= vitvs_op_residual_ln(prec, a[q].x, a[q].part, s_fc2, bias, nullptr, gamma, beta, a[q].xn, M, D, 1e-6f, st[q]);
             return rc; }},
     };
+    printf("rows per launch %d, split-K slices proj %d fc2 %d\n", M, s_proj, s_fc2);
     printf("%-40s %28s %28s %28s\n", "us per launch: per queue / overall", "1 queue", "2 queues", "3 queues");
     for (auto& op : ops) {
         const int n = op.launches == 7 ? reps / 4 : reps;
