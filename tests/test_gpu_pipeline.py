@@ -121,6 +121,34 @@ def test_staged_inputs_replay_one_graph_per_slot_whatever_buffers_the_caller_bri
     pipe.close()
 
 
+def test_many_token_updates_side_by_side_are_reproducible():
+    """DINO ViT-B/8 448² (3137 tokens: the key-split long-sequence attention with its fence-free hand-off, the 256-row GEMM tiles, the
+    f16 split Gram) with three updates in flight: every result equals the first pass of its (frame pair, visiting order), whichever
+    slot computed it and whatever ran beside it."""
+    dev = torch.device("cuda", 0)
+    cfg = config.baseline_config("vitb8_448")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, 0)
+    seeds = [synth.ACCEPTED_FRAME_SEEDS["vitb8_448"] + i for i in range(2)]
+    _, _, des, cur, Z, K = _inputs(cfg, params, seeds, dev)
+    P = 4                                                         # (pair, order) cases; 4 and the depth 3 are coprime
+    orders = _orders(cfg, P, dev)
+    pipe = UpdatePipeline(cfg, params, sd, precision="bf16", depth=3)
+    first, tickets = {}, []
+    for i in range(36):
+        tickets.append((i, pipe.submit(cur[i % 2], des[i % 2], Z, K, _lib.SELECT_ORDER, orders[i % P])))
+        if len(tickets) == 3:
+            j, t = tickets.pop(0)
+            v, st = pipe.result(t)
+            assert int(st[0]) == _lib.STATUS_OK
+            assert first.setdefault(j % P, v.cpu().numpy().tobytes()) == v.cpu().numpy().tobytes(), f"update {j}"
+    for j, t in tickets:
+        v, _ = pipe.result(t)
+        assert first.setdefault(j % P, v.cpu().numpy().tobytes()) == v.cpu().numpy().tobytes(), f"update {j}"
+    assert len(set(first.values())) == P
+    pipe.close()
+
+
 def test_tickets_options_and_cached_goal():
     dev = torch.device("cuda", 0)
     blob = load_golden("e2e_vitb16_224.npz")                    # an accepted pair: arg-max margins above the fp32 noise
