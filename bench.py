@@ -644,6 +644,20 @@ def run_rank(args):
             dist.all_reduce(seen, op=dist.ReduceOp.SUM)
             ranks_seen = int(seen.item())
 
+        # what one update takes on its queue while the others share the chip (device time between two events on the slot's stream)
+        lat_in_flight = None
+        if pipe is not None and not multi:
+            evs = []
+            for i in range(10 * in_flight):
+                st_k = pipe.streams[pipe.submitted % in_flight]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st_k)
+                pipe_step(i)
+                e1.record(st_k)
+                evs.append((e0, e1))
+            pipe_fence()
+            lat_in_flight = float(np.median([a.elapsed_time(b) for a, b in evs[2 * in_flight:]]))
+
         # single-update latency with a host synchronisation per update (a control loop's view)
         lat = []
         for i in range(10):
@@ -833,6 +847,7 @@ def run_rank(args):
                   weight_bytes=cfg.weight_elems() * es,
                   weight_stream_frac_of_hbm_peak=round(cfg.weight_elems() * es * value / world / B / PEAK_HBM, 5)),
         latency_ms_with_host_sync=round(float(np.median(lat)) * 1e3, 4),
+        latency_ms_per_update_in_flight=None if lat_in_flight is None else round(lat_in_flight, 4),
         kernels=kernels,
         status=[int(s) for s in status_host],
         v_c=[float(x) for x in v_host[0]],
