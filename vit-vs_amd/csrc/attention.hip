@@ -939,6 +939,10 @@ static AttnPlan attention_plan(int n_img, int N, int H) {
     return best;
 #endif
     if (N < 512) return best;                                   // short sequences in batches: whole items (tools/big_ops attnmid)
+    // Beside other queues' launches (vitvs_set_option "in_flight") the chip is filled by THEIR workgroups: whole items, no hand-off
+    // (three updates in flight, same box: ViT-B/8 448² 419 -> 436 updates/s, ViT-L/14 518² 703 -> 732; the 64-query kernel of the
+    // mid sizes keeps its two key groups: ViT-S/14 308² 4480 -> 4333 without them)
+    if (g_updates_in_flight >= 2) return best;
     double best_cost = 1e30;
     for (int sp : {1, 2, 4}) {
         if (sp > 1 && nt / sp < 4) break;
