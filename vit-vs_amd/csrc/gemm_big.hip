@@ -457,6 +457,11 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
     // 192 x 256 (code 1256), priced 0.9: 2740 x 4096 x 1024 (N is not a multiple of 192): 240 tiles 27.6 us against 176 of
     // 256 x 256 -> 29.8 us; level with 256 x 192 where that applies (3152 x 3072: 21.7 / 21.6 us)
     if (N % 256 == 0 && 0.9 * rounds((long)((M + 191) / 192) * (N / 256) * splits) < cost) best = 1256;
+    // Everything above balances ONE launch over the chip.  Beside other queues' launches (vitvs_set_option "in_flight") the
+    // other queues' workgroups fill what a launch leaves idle, and the tile with the fewest operand bytes per FLOP wins: three
+    // updates in flight, same box, 256 x 256 for every layer it divides: 8 / 6 / 4 pairs 8607 -> 9249 / 7980 -> 8730 / 7385 -> 7760
+    // updates/s, ViT-B/8 448² 438 -> 460, ViT-L/14 518² 731 -> 793 (3 pairs, 1182 rows = 4.6 row tiles: 6787 -> 6664, hence the bound).
+    if (g_updates_in_flight >= 2 && N % 256 == 0 && M >= 1536) best = 256;
     return best;
 }
 
