@@ -47,7 +47,8 @@ struct Acts { void *xn, *qkv, *attn, *hid; float *x, *part; };
 static int queues_mode(int prec) {
     const size_t es = prec == VITVS_F32 ? 4 : 2;
     const int n_img = getenv("OPC_IMAGES") ? atoi(getenv("OPC_IMAGES")) : 2;   // OPC_IMAGES=1: one frame per chain (197 rows)
-    const int N = 197, M = n_img * N, D = 768, H = 12, hidden = 3072, reps = 240;
+    if (getenv("OPC_HINT")) vitvs_op_plan_in_flight(atoi(getenv("OPC_HINT")));   // plan as a handle with that "in_flight" option
+    const int N = 197, M = n_img * N, D = 768, H = 12, hidden = 3072, reps = n_img > 4 ? 60 : 240;
     int lo = 0, hi = 0;
     CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     hipStream_t st[3];
