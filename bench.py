@@ -222,6 +222,8 @@ def split_k(m, n, k, bk, in_flight=1):
         for c in (2, 3, 4):
             if k % (c * 64) == 0 and k // c >= 8 * 64 and t128 * c <= 256:
                 pick = c
+        if in_flight >= 2 and pick > 2 and m >= 2048:
+            pick = 2
         if pick > 1:
             return pick
     tiles = -(-m // 64) * (n // 64)

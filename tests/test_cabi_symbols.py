@@ -80,8 +80,8 @@ def test_bench_split_k_mirror_matches_the_library_plan():
     # ... and under the plan hint of a handle whose updates run beside others (vitvs_set_option "in_flight")
     assert lib.vitvs_op_plan_in_flight(3) == 1
     try:
-        for m in (197, 394, 788, 3152):
-            for n, k in ((768, 768), (768, 3072), (384, 1536)):
+        for m in (197, 394, 788, 1576, 2364, 3152, 2740, 6274):
+            for n, k in ((768, 768), (768, 3072), (384, 1536), (1024, 4096)):
                 assert bench.split_k(m, n, k, 64, 3) == lib.vitvs_op_splitk_slices(_lib.BF16, m, n, k), (m, n, k)
         t = (ctypes.c_int32 * 3)()
         assert lib.vitvs_op_linear_tile(_lib.BF16, 394, 2304, 768, 0, t) == 0 and list(t) == [64, 64, 1]   # 4-wave workgroups

@@ -476,6 +476,10 @@ int splitk_slices(Precision p, int M, int N, int K) {
             if (K % (c * 64) != 0 || K / c < 8 * 64) continue;
             if (t128 * c <= 256) pick = c;
         }
+        // Beside other queues' launches (vitvs_set_option "in_flight"), from ~2000 rows on, a third slice costs more in partial sums
+        // (residual_ln is at the HBM rate there and does not overlap with anything) than it gains in fill: three in flight, same
+        // box, 8 / 6 pairs 9108 -> 9578 / 8640 -> 9105 updates/s with two; 4 pairs (1576 rows, 4 slices) 7610 -> 7248: not there.
+        if (g_updates_in_flight >= 2 && pick > 2 && M >= 2048) pick = 2;
         if (pick > 1) return pick;
     }
     // The most K slices that still put at most one workgroup on every CU (each slice >= 4 k-tiles);
