@@ -221,7 +221,8 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
  *                          use 4-wave workgroups (half the LDS: two launches of different queues share a CU), the narrow
  *                          layers two K slices and a grid order that keeps a weight tile in one XCD's L2, and the
  *                          long-sequence attention whole query blocks (no key ranges to merge), the many-row layers
- *                          256 x 256 tiles wherever they divide (fewest operand bytes per FLOP instead of launch balance).
+ *                          256 x 256 tiles wherever they divide (fewest operand bytes per FLOP instead of launch balance)
+ *                          and at most two K slices.
  * Returns 0, or -5 for an unknown name / a value out of range. */
 VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value);
 /* The handles of such an arrangement run ONE network: `h` (created with the same network, input geometry and precision, no
