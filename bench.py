@@ -149,11 +149,6 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
     envs = rank_environments(n, free_port())
     logdir = tempfile.mkdtemp(prefix="vitvs_bench_")
     procs, outs, errs = [], [], []
-    for r, env in enumerate(envs):
-        outs.append(open(os.path.join(logdir, f"rank{r}.out"), "w+"))
-        errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
-        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=outs[r], stderr=errs[r], text=True, start_new_session=True))
 
     def tail(fh, lines=15):
         fh.flush()
@@ -161,54 +156,107 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
         return "".join(fh.readlines()[-lines:])
 
     def stop_all():
+        """Every rank runs in a session of its own (so that a signal aimed at this launcher's group cannot take a rank down
+        half-way through a collective while the others wait): ending them is therefore this process's job on EVERY way out —
+        a failed rank, the deadline, SIGTERM / SIGINT to the launcher, an exception.  SIGTERM to each rank's process group,
+        SIGKILL after 5 s."""
+        import signal
         for p_ in procs:
             if p_.poll() is None:
-                p_.terminate()
+                try:
+                    os.killpg(p_.pid, signal.SIGTERM)      # pid == pgid == sid of the rank (start_new_session)
+                except (ProcessLookupError, PermissionError):
+                    p_.terminate()
         t_end = time.monotonic() + 5.0
         for p_ in procs:
             try:
                 p_.wait(timeout=max(0.1, t_end - time.monotonic()))
             except subprocess.TimeoutExpired:
-                p_.kill()
+                try:
+                    os.killpg(p_.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    p_.kill()
                 p_.wait()
 
-    t_stop = time.monotonic() + deadline_s
-    failed = None
-    while True:
-        codes = [p_.poll() for p_ in procs]
-        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            failed = bad[0]
-            break
-        if all(c == 0 for c in codes):
-            break
-        if time.monotonic() > t_stop:
-            failed = -1
-            break
-        time.sleep(poll_s)
-    if failed is not None:
-        stop_all()
-        if failed < 0:
-            print(f"bench.py: no result after {deadline_s:.0f} s; ranks terminated. rank 0 stderr tail:\n{tail(errs[0])}", file=sys.stderr)
-        else:
-            print(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; the other ranks were terminated. "
-                  f"Its stderr tail:\n{tail(errs[failed])}", file=sys.stderr)
-        return 1
-    out0 = tail(outs[0], lines=50)
-    for r in range(n):
-        t_ = tail(errs[r], lines=5)
-        if t_.strip() and os.environ.get("VITVS_BENCH_VERBOSE") == "1":
-            print(f"[rank {r} stderr] {t_}", file=sys.stderr)
-    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
-    if not line:
-        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
-        return 1
-    parsed = json.loads(line[-1])
-    if parsed.get("n_gpus") != n:
-        print(f"bench.py: rank 0 reported n_gpus={parsed.get('n_gpus')} for --gpus {n}", file=sys.stderr)
-        return 1
-    print(line[-1])
-    return 0
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Signalled(signum)
+
+    import signal
+    previous = {}
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            previous[sig] = signal.signal(sig, on_signal)
+        except (ValueError, OSError):                      # not the main thread (the unit tests call this function directly)
+            pass
+    rc, keep_logs = 1, True
+    try:
+        for r, env in enumerate(envs):
+            outs.append(open(os.path.join(logdir, f"rank{r}.out"), "w+"))
+            errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
+            procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=outs[r], stderr=errs[r], text=True, start_new_session=True))
+        t_stop = time.monotonic() + deadline_s
+        failed = None
+        while True:
+            codes = [p_.poll() for p_ in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_stop:
+                failed = -1
+                break
+            time.sleep(poll_s)
+        if failed is not None:
+            stop_all()
+            if failed < 0:
+                print(f"bench.py: no result after {deadline_s:.0f} s; ranks terminated. rank 0 stderr tail:\n{tail(errs[0])}", file=sys.stderr)
+            else:
+                print(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; the other ranks were terminated. "
+                      f"Its stderr tail:\n{tail(errs[failed])}", file=sys.stderr)
+            return 1
+        out0 = tail(outs[0], lines=50)
+        for r in range(n):
+            t_ = tail(errs[r], lines=5)
+            if t_.strip() and os.environ.get("VITVS_BENCH_VERBOSE") == "1":
+                print(f"[rank {r} stderr] {t_}", file=sys.stderr)
+        line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+        if not line:
+            print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+            return 1
+        parsed = json.loads(line[-1])
+        if parsed.get("n_gpus") != n:
+            print(f"bench.py: rank 0 reported n_gpus={parsed.get('n_gpus')} for --gpus {n}", file=sys.stderr)
+            return 1
+        print(line[-1])
+        rc, keep_logs = 0, False
+        return 0
+    except _Signalled as sig:
+        print(f"bench.py: signal {sig.args[0]} received; terminating the ranks", file=sys.stderr)
+        rc = 128 + int(sig.args[0])
+        return rc
+    finally:
+        stop_all()                                          # no rank outlives the launcher, whichever way it leaves
+        for fh in outs + errs:
+            try:
+                fh.close()
+            except OSError:
+                pass
+        if not keep_logs:
+            import shutil
+            shutil.rmtree(logdir, ignore_errors=True)
+        elif rc != 0:
+            print(f"bench.py: per-rank logs kept in {logdir}", file=sys.stderr)
+        for sig, h_ in previous.items():
+            try:
+                signal.signal(sig, h_)
+            except (ValueError, OSError):
+                pass
 
 
 # ----------------------------------------------------------------------------------------------- work model

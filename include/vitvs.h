@@ -227,8 +227,10 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
 VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value);
 /* The handles of such an arrangement run ONE network: `h` (created with the same network, input geometry and precision, no
  * tensors uploaded) borrows the device weights of `src` instead of holding a copy — one set of weights stays resident in
- * the Infinity Cache for all queues (a copy per handle: 4 x 172 MB cycle through its 256 MB).  `src` must own its weights,
- * have all of them (vitvs_weights_ready) and outlive `h`; uploads go to `src` only (vitvs_set_tensor on `h` is error -5). */
+ * the Infinity Cache for all queues (a copy per handle: 4 x 172 MB cycle through its 256 MB).  `src` must own its weights and
+ * have all of them (vitvs_weights_ready); uploads go to `src` only (vitvs_set_tensor on `h` is error -5).  Ownership is shared:
+ * the device memory is released when the LAST handle holding it is destroyed, so `src` and `h` may be destroyed in any order
+ * (a borrower whose lender is gone keeps working; nothing can upload to those weights any more). */
 VITVS_API int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src);
 
 /* --- measurement hooks (bench.py roofline leg) --------------------------------------------------

@@ -158,3 +158,42 @@ def test_launcher_parent_never_imports_torch():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "VITVS_BENCH_SHARE_GPU")}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert r.stdout.strip().splitlines()[-1] == "False 2", (r.stdout, r.stderr)
+
+
+def test_sigterm_to_the_launcher_leaves_no_rank_behind(tmp_path):
+    """The ranks run in sessions of their own, so a signal to the launcher's process group does not reach them: the launcher
+    itself must end them when it is told to stop (harness time limit, Ctrl-C, job cancel) — and remove nothing it still
+    needs for the post-mortem.  A real parent process here: SIGTERM to it, then every rank's pid must be gone."""
+    import signal
+    import subprocess
+    import time
+    pids = tmp_path / "pids"
+    pids.mkdir()
+    stub = _stub(tmp_path, f"""
+        import os, time
+        open(os.path.join({str(pids)!r}, os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+    """)
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import importlib.util, sys
+        spec = importlib.util.spec_from_file_location("bench_mod_sig", {os.path.join(ROOT, "bench.py")!r})
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        bench.visible_devices = lambda: 3
+        sys.exit(bench.launch_ranks(bench.parse_args(["--gpus", "3"]), ["--gpus", "3"], script={stub!r}))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "VITVS_BENCH_SHARE_GPU")}
+    parent = subprocess.Popen([sys.executable, str(driver)], env=env, stderr=subprocess.PIPE, text=True)
+    t_end = time.monotonic() + 60.0
+    while len(os.listdir(pids)) < 3 and time.monotonic() < t_end:
+        time.sleep(0.1)
+    assert len(os.listdir(pids)) == 3, "the ranks never started"
+    time.sleep(0.3)                                             # (a pid file exists a moment before it has its content)
+    rank_pids = [int((pids / r).read_text()) for r in ("0", "1", "2")]
+    parent.send_signal(signal.SIGTERM)
+    _, err = parent.communicate(timeout=30)
+    assert parent.returncode == 128 + signal.SIGTERM and "terminating the ranks" in err
+    for pid in rank_pids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,21 @@ struct Block {
     void *qkvw = nullptr, *projw = nullptr, *fc1w = nullptr, *fc2w = nullptr;
 };
 
+// Device memory of one set of weights.  Held through a shared_ptr by the handle that uploaded it AND by every handle that
+// borrows it (vitvs_share_weights): the memory is freed when the LAST holder is destroyed, in whatever order the handles go,
+// so a borrower's kernels and captured graphs never read freed weights.
+struct WeightStore {
+    int device = 0;
+    std::vector<void*> allocs;
+    ~WeightStore() {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        if (prev != device) (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        if (prev != device && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace vitvs
 
 using namespace vitvs;
@@ -65,7 +81,8 @@ struct vitvs_handle {
     int device = 0;
     int grid = 0, T = 0, N = 0, Kp = 0, Dp = 0, hidden = 0, n_img_max = 0;
     std::string err;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                      // workspaces, outputs, staging: this handle's own
+    std::shared_ptr<WeightStore> wstore;            // the weights: shared with the handles that borrow them
     std::map<std::string, bool> have;
     int desc_keys = -1;   // >= 0 while a velocity update runs: the forward's last launch emits the descriptors and clears this many keys
     bool ready = false;       // cached result of vitvs_weights_ready (reset by vitvs_set_tensor)
@@ -145,19 +162,28 @@ struct DeviceScope {
 };
 
 template <typename T>
-int dev_alloc(vitvs_handle* h, T** out, size_t count) {
+int dev_alloc_into(std::vector<void*>& owner, T** out, size_t count) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, count * sizeof(T) + 256);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc", __FILE__, __LINE__);
-    h->allocs.push_back(p);
+    owner.push_back(p);
     (void)hipMemset(p, 0, count * sizeof(T) + 256);   // detail rows a call does not write read as zeros, not as stale memory
     *out = reinterpret_cast<T*>(p);
     return 0;
 }
+template <typename T>
+int dev_alloc(vitvs_handle* h, T** out, size_t count) { return dev_alloc_into(h->allocs, out, count); }
+
+// frees one of the handle's own blocks (not a weight) and forgets it
+void dev_free(vitvs_handle* h, void* p) {
+    if (!p) return;
+    h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), p), h->allocs.end());
+    (void)hipFree(p);
+}
 
 int upload_f32(vitvs_handle* h, float** dst, const float* src, size_t n) {
     if (!*dst) {
-        int rc = dev_alloc(h, dst, n);
+        int rc = dev_alloc_into(h->wstore->allocs, dst, n);
         if (rc) return rc;
     }
     VITVS_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
@@ -169,7 +195,7 @@ int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, si
     const size_t es = elem_size(h->prec);
     if (!*dst) {
         unsigned char* p = nullptr;
-        int rc = dev_alloc(h, &p, rows * ld * es);
+        int rc = dev_alloc_into(h->wstore->allocs, &p, rows * ld * es);
         if (rc) return rc;
         *dst = p;
     }
@@ -271,10 +297,8 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     const vitvs_config& c = h->cfg;
     const int D = c.dim;
     int rc = 0;
-#ifndef VITVS_PROBE_SKIP_PATCHIFY   // probe builds (tools/measure_round.sh): what removing this launch could save at most
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCHIFY, st);
         rc = launch_patchify(h->prec, cx[k].pa, cx[k].rs, cx[k].Ape, cx[k].x, st); }
-#endif
     // Patch embedding as a split-K GEMM (more workgroups than its 84 output tiles), finished together with
     // cls / pos_embed and block 0's norm1 by one residual_ln-style launch.
     // Block i: qkv -> attention -> proj (split-K partials) -> [residual + norm2] -> fc1+GELU ->
@@ -391,9 +415,7 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     a.sel_out = h->sel_out; a.s_uv = h->s_uv; a.feat = h->feat; a.L_ws = h->Lws; a.max_rows = c.max_rows;
     h->last_pairs = n_pairs; h->last_T = T;
     int rc = 0;
-#ifndef VITVS_PROBE_SKIP_SERVO      // probe builds: the update without its last launch (upper bound of a Gram + servo fusion)
     { Span sp(h, KC_SERVO, st); rc = launch_servo(a, st); }
-#endif
     if (rc) return set_err(h, rc, "servo launch failed (LDS budget or bad arguments)");
     return 0;
 }
@@ -424,6 +446,8 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->prec = to_prec(cfg->precision);
     (void)hipGetDevice(&h->device);
     g_current_device = h->device;
+    h->wstore = std::make_shared<WeightStore>();
+    h->wstore->device = h->device;
     h->grid = 1 + (cfg->img_size - cfg->patch) / cfg->stride;
     h->T = h->grid * h->grid;
     h->N = h->T + 1;
@@ -452,12 +476,17 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 #undef ALLOC_BYTES
     if (!rc) rc = dev_alloc(h, &h->x, M * D);
     if (!rc) rc = dev_alloc(h, &h->part, (size_t)8 * M * D);   // at most 8 split-K slices (splitk_slices)
-    {   // the key-split plan depends on the image count of a call: size for the largest need over 1 .. n_img_max
+    {   // the key-split plan depends on the image count of a call: size for the largest need over 1 .. n_img_max, under the
+        // plan of a handle that runs ALONE (in_flight 1: the divided plan, the only one that needs a workspace) — whatever hint
+        // the calling thread carries (vitvs_op_plan_in_flight) and whatever `in_flight` the handle is given later
+        const int thread_hint = g_updates_in_flight;
+        g_updates_in_flight = 1;
         size_t f = 0, t = 0;
         for (int n = 1; n <= h->n_img_max; ++n) {
             f = std::max(f, attention_workspace_floats(n, h->N, cfg->heads));
             t = std::max(t, attention_ticket_count(n, h->N, cfg->heads));
         }
+        g_updates_in_flight = thread_hint;
         if (!rc && f) rc = dev_alloc(h, &h->attn_ws.state, f);
         if (!rc && t) rc = dev_alloc(h, &h->attn_ws.tickets, t);   // dev_alloc zeroes: the tickets start at 0
     }
@@ -525,6 +554,7 @@ int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src) {
     h->blk = src->blk;
     h->pe_w = src->pe_w; h->pe_b = src->pe_b; h->cls = src->cls; h->pos = src->pos;
     h->have = src->have;
+    h->wstore = src->wstore;                    // shared ownership: the weights outlive whichever of the two is destroyed first
     h->ready = true;
     h->borrowed = true;
     return 0;
@@ -653,8 +683,7 @@ static int resize_tables(vitvs_handle* h, ResizeArgs& t, int in_h, int in_w) {
     for (const int** d : {&t.xb, &t.xk, &t.yb, &t.yk}) {
         if (*d) {
             VITVS_HIP_CHECK(hipDeviceSynchronize());   // a launch on ANY stream may still read them
-            h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*d), h->allocs.end());
-            (void)hipFree((void*)*d);
+            dev_free(h, (void*)*d);
             *d = nullptr;
         }
     }
@@ -696,27 +725,40 @@ int vitvs_set_frame_size(vitvs_handle* h, int32_t in_h, int32_t in_w) {
     DeviceScope dev(h);
     if (in_h == h->cfg.img_size && in_w == h->cfg.img_size) in_h = in_w = 0;   // nothing to resize: the plain patch-row build
     if (in_h == h->fr.in_h && in_w == h->fr.in_w) return 0;
-    // captured updates hold the previous tables' addresses: they go (a cached goal's tokens do not depend on the geometry and stay)
+    // Everything the new geometry needs is built FIRST; the handle changes only once nothing can fail any more, so an error
+    // (tables, the LDS limit of the fused resize, the staging allocation) leaves the previous geometry fully usable.
+    ResizeArgs fresh{};
+    if (int rc = resize_tables(h, fresh, in_h, in_w)) return rc;
+    if (fresh.in_h && (size_t)fresh.rows * h->cfg.patch * 3 > 64 * 1024) {
+        (void)resize_tables(h, fresh, 0, 0);
+        return set_err(h, -3, "camera frame too large for the fused resize (use vitvs_resize_frames_dev)");
+    }
+    const size_t need = fresh.in_h ? (size_t)fresh.in_h * fresh.in_w * 3 : (size_t)h->cfg.img_size * h->cfg.img_size * 3;
+    uint8_t *new_cur = nullptr, *new_des = nullptr;
+    if (need > h->staged_frame_bytes) {             // host-buffer entry points stage whole frames
+        const size_t P = (size_t)h->cfg.max_pairs;
+        if (dev_alloc(h, &new_cur, P * need) || dev_alloc(h, &new_des, P * need)) {
+            dev_free(h, new_cur);
+            (void)resize_tables(h, fresh, 0, 0);
+            return set_err(h, -6, "frame staging allocation failed (the previous frame geometry stays in place)");
+        }
+    }
+    // commit.  Captured updates hold the previous tables' addresses: they go (a cached goal's tokens do not depend on the
+    // geometry and stay)
     VITVS_HIP_CHECK(hipDeviceSynchronize());
     for (auto& g : h->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     h->graphs.clear();
-    if (int rc = resize_tables(h, h->fr, in_h, in_w)) return rc;
-    if (h->fr.in_h && (size_t)h->fr.rows * h->cfg.patch * 3 > 64 * 1024) {
-        (void)resize_tables(h, h->fr, 0, 0);
-        return set_err(h, -3, "camera frame too large for the fused resize (use vitvs_resize_frames_dev)");
-    }
-    if (frame_bytes(h) > h->staged_frame_bytes) {   // host-buffer entry points stage whole frames
-        const size_t P = (size_t)h->cfg.max_pairs;
-        for (uint8_t** b : {&h->st_cur, &h->st_des}) {
-            h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)*b), h->allocs.end());
-            (void)hipFree(*b);
-            *b = nullptr;
-            if (dev_alloc(h, b, P * frame_bytes(h))) return set_err(h, -6, "frame staging allocation failed");
-        }
-        h->staged_frame_bytes = frame_bytes(h);
+    (void)resize_tables(h, h->fr, 0, 0);            // frees the previous tables
+    h->fr = fresh;
+    if (new_cur) {
+        dev_free(h, h->st_cur);
+        dev_free(h, h->st_des);
+        h->st_cur = new_cur;
+        h->st_des = new_des;
+        h->staged_frame_bytes = need;
     }
     return 0;
 }

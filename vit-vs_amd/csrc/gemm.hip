@@ -61,12 +61,10 @@ struct EpiStore {
     template <bool WT>
     __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-#ifndef VITVS_DBG_NO_GELU       // experiment builds: what the activation's arithmetic costs (results are wrong without it)
         if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
-#endif
         store4<T, WT>(out + (size_t)m * ldo + n, v);
     }
 };
@@ -142,11 +140,7 @@ struct EpiPartial {
 __device__ unsigned long long* g_gemm_probe;
 #endif
 
-#ifdef VITVS_DBG_NO_WT        // experiment builds: plain stores instead of write-through ones in the 64-row epilogues
-#define VITVS_EPI_WT(BM) false
-#else
 #define VITVS_EPI_WT(BM) ((BM) < 128)
-#endif
 template <typename T, int BM, int BN, int KG, class Epi, int NS = 0>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
@@ -234,11 +228,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
         for (int mi = 0; mi < Tile::MT; ++mi) {
             if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
             const int m = m0 + wm * Tile::WM + mi * 16 + (lane & 15);
-#ifdef VITVS_DBG_NO_EPI
-            if (m < M && n < N && acc[ni][mi][0] == 1234.5f) epi.template store<VITVS_EPI_WT(BM)>(m, n, acc[ni][mi], col[ni]);
-#else
             if (m < M && n < N) epi.template store<VITVS_EPI_WT(BM)>(m, n, acc[ni][mi], col[ni]);   // 64-row tiles: one-wave launches
-#endif
         }
     }
 #ifdef VITVS_PROBE
@@ -295,11 +285,6 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
     // share it: ViT-B/16 224², 3 updates in flight 3113 -> 3392 updates/s, but 2220 -> 2078 on one stream (same box,
     // profiles/r03_notes.md section 5), hence by the caller's hint and not by default.
     int kg = (g_updates_in_flight < 2 && wgs <= 256 && nk_per_slice >= 4 && nk_per_slice % 2 == 0) ? 2 : 1;
-#ifdef VITVS_PLAN_ENV                         // experiment builds only (tools/two_streams.py): plan overrides from the environment
-    if (const char* e = getenv("VITVS_X_BN")) { const int v = atoi(e); if (v && !fixed64 && N % v == 0) bn = v; }
-    if (const char* e = getenv("VITVS_X_KG")) { const int v = atoi(e); if (v) kg = v; }
-    if (kg == 2 && (nk_per_slice < 4 || nk_per_slice % 2)) kg = 1;
-#endif
     return TilePlan{bn, kg};
 }
 
@@ -314,9 +299,6 @@ struct EpiArgs {   // host image of the flat epilogue arguments
 template <class Epi> constexpr bool xcd_mapped() { return false; }
 template <> constexpr bool xcd_mapped<EpiPartial>() { return true; }
 static bool want_xcd_map() {
-#ifdef VITVS_PLAN_ENV
-    if (const char* e = getenv("VITVS_X_XCDMAP")) return atoi(e) != 0;
-#endif
     // Beside other queues' launches the narrow layers are bound by what their private L2s fetch, not by latency (fc2 at three
     // queues 4.48 -> 3.67 us per launch, 3932 -> 4072 updates/s); alone, XCD balance comes first (round 1: the map lost).
     // (A column-class map for the one-slice launches — qkv's 36 column tiles over 8 XCDs — lost: 3.13 -> 3.37 us.)
@@ -324,9 +306,6 @@ static bool want_xcd_map() {
 }
 
 static bool want_staged_epilogue(int kg) {
-#ifdef VITVS_PLAN_ENV
-    if (const char* e = getenv(kg == 2 ? "VITVS_X_STAGED2" : "VITVS_X_STAGED")) return atoi(e) != 0;
-#endif
     // 4-wave workgroups: measured faster alone and side by side (qkv 6.00 -> 5.11 us alone, 3.07 -> 2.81 at three queues; fc1
     // 8.62 -> 7.16, 3.99 -> 3.39; 2 pairs +3 % on one stream and +10 % with three updates in flight; never slower)
     // 8-wave workgroups (two k-groups, the one-stream plan): +1.4 % updates/s on one stream (2202 -> 2233, three interleaved rounds)
@@ -363,9 +342,6 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
 // In the forward (kernel trace, same box): 8-pair proj 11.40 / 11.47 / 11.31 us, 2-pair fc1 19.8 / 13.5 / 12.2 us; end to end
 // against 4 stages everywhere: 8 pairs +0.9 ... +1.3 % with 3 or 2 stages, 2 pairs +1.6 % (profiles/r03_notes.md).
 static int ring_stages(int bn, long wgs) {
-#ifdef VITVS_RING_FIXED                       // experiments (tools/): one depth for every one-k-group 64-row launch (0 = the default, 4)
-    return VITVS_RING_FIXED;
-#endif
     if (wgs <= 256) return 0;                 // the tile's default
     if (bn == 128) return 2;
     return wgs <= 512 ? 3 : 2;
@@ -373,9 +349,6 @@ static int ring_stages(int bn, long wgs) {
 
 // Many-row problems (many frame pairs, 448² / 518² inputs): 128x128 tiles halve the LDS and L2 bytes per MFMA.
 static bool big_problem(int M, int N, int splits) {
-#ifdef VITVS_PLAN_ENV
-    if (const char* e = getenv("VITVS_X_128")) { if (atoi(e) && N % 128 == 0) return true; }
-#endif
     // >= 256 tiles: with 2 workgroups per CU that is one round on every CU or more (measured: 294 tiles -12 %, 176 tiles
     // +37 % against 64x64 tiles)
     return splits == 1 && (N % 128) == 0 && (long)((M + 127) / 128) * (N / 128) >= 256;
@@ -397,9 +370,6 @@ static int launch_tiles(const T* A, const T* W, int M, int N, int K, const EpiAr
     if (big_problem(M, N, splits)) return launch_one<T, 128, 1, Epi, 128>(A, W, M, N, K, epi, stream, splits);
     const TilePlan pl = plan_tiles(M, N, K / splits / bk, splits, fixed64);
     int ns = pl.kg == 1 ? ring_stages(pl.bn, (long)((M + 63) / 64) * (N / pl.bn) * splits) : 0;
-#ifdef VITVS_PLAN_ENV
-    if (const char* e = getenv("VITVS_X_NS")) { if (pl.kg == 1 && atoi(e)) ns = atoi(e); }
-#endif
     if (pl.bn == 128) {
         if (pl.kg == 2) return launch_one<T, 128, 2, Epi>(A, W, M, N, K, epi, stream, splits);
         if (ns == 2) return launch_one<T, 128, 1, Epi, 64, 2>(A, W, M, N, K, epi, stream, splits);
@@ -485,9 +455,6 @@ int splitk_slices(Precision p, int M, int N, int K) {
     // The most K slices that still put at most one workgroup on every CU (each slice >= 4 k-tiles);
     // none if the tiles alone already cover the chip.
     const long tiles = (long)((M + 63) / 64) * (N / 64);
-#ifdef VITVS_PLAN_ENV
-    if (const char* e = getenv("VITVS_X_SPLITS")) { const int v = atoi(e); if (v && K % (v * bk) == 0 && K / v >= 4 * bk) return v; }
-#endif
     int best = 1;
     for (int c : {2, 3, 4, 6, 8}) {
         if ((K % (c * bk)) != 0 || K / c < 4 * bk) continue;
@@ -513,9 +480,6 @@ int launch_linear_partial_classic(Precision p, const void* A, const void* W, flo
     const EpiArgs e{part, nullptr, nullptr, 0};
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
     if (p == PREC_F16) return launch_tiles64<f16, EpiPartial>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
-#ifdef VITVS_PLAN_ENV
-    if (getenv("VITVS_X_PBN")) return launch_tiles<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
-#endif
     return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
 }
 

@@ -56,13 +56,7 @@ struct GemmTile {
     // workgroups per CU, measured -24 ... -27 % on the 6274-row fc1 / qkv GEMMs against 4 stages (1 workgroup per CU).
     // NS > 0 overrides the depth: the launchers of gemm.hip pick a shallower ring for 64-row launches of more than one
     // workgroup per CU, where the LDS footprint decides how many are resident (ring_stages() there has the measurements).
-#ifndef VITVS_KG2_STAGES                      // experiments (tools/two_streams.py): ring depth of the two-k-group tiles
-#define VITVS_KG2_STAGES 3
-#endif
-#ifndef VITVS_LDS_CAP                         // ... and the footprint above which the swap area reuses the rings
-#define VITVS_LDS_CAP (160 * 1024)
-#endif
-    static constexpr int NST = NS ? NS : ((BM >= 128) ? 2 : ((KG == 1) ? 4 : VITVS_KG2_STAGES));
+    static constexpr int NST = NS ? NS : ((BM >= 128) ? 2 : ((KG == 1) ? 4 : 3));
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int GROUP_BYTES = NST * STAGE_BYTES;
     static constexpr int RING_BYTES = KG * GROUP_BYTES;
@@ -70,7 +64,7 @@ struct GemmTile {
     // needed before the swap's writes while other waves still read their last stage)
     static constexpr int SWAP_SLOTS = (NT * MT + 1) / 2;            // accumulator tiles a wave hands over
     static constexpr int SWAP_BYTES = (KG == 2) ? SWAP_SLOTS * 16 * 512 : 0;
-    static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > VITVS_LDS_CAP;   // no room: reuse the rings (one more barrier)
+    static constexpr bool SWAP_ALIAS = RING_BYTES + SWAP_BYTES > 160 * 1024;   // no room: reuse the rings (one more barrier)
     static constexpr int SWAP_OFFSET = SWAP_ALIAS ? 0 : RING_BYTES;
     static constexpr int LDS_BYTES = SWAP_ALIAS ? (RING_BYTES > SWAP_BYTES ? RING_BYTES : SWAP_BYTES) : RING_BYTES + SWAP_BYTES;
     static constexpr int THREADS = 256 * KG;
@@ -156,17 +150,12 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         if (younger >= 2) wait_vmcnt<2 * L>();
         else if (younger == 1) wait_vmcnt<L>();
         else wait_vmcnt<0>();
-#ifndef VITVS_DBG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         if (ts && kt == 0) ts[2] = __builtin_readcyclecounter();
         // every wave has finished reading the stage tile kt - 1 used: refill it with tile kt + NST - 1
         if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
         const unsigned char* sa = ring + stage * Tile::STAGE_BYTES;
         const unsigned char* sb = sa + BM * 128;
-#ifdef VITVS_DBG_NO_LDSREAD
-        if (kt >= 0) { stage = (stage + 1 == NST) ? 0 : stage + 1; continue; }
-#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int c = 4 * s + (lane >> 4);
@@ -181,11 +170,7 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
             for (int ni = 0; ni < Tile::NT; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < Tile::MT; ++mi) {
-#ifdef VITVS_DBG_NO_MFMA
-                    acc[ni][mi][0] += __uint_as_float(wf[ni][0] ^ xf[mi][1]);
-#else
                     acc[ni][mi] = mma_chunk<T>(acc[ni][mi], wf[ni], xf[mi]);
-#endif
                 }
         }
         stage = (stage + 1 == NST) ? 0 : stage + 1;

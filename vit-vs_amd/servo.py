@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .config import ServoParams
-from .engine import Engine
+from .engine import Engine, VitvsError
 
 STATUS_NAMES = {0: "ok", 1: "no_correspondence", 2: "too_few_features", 3: "no_depth"}
 
@@ -220,8 +220,14 @@ class Controller:
             arrs.append(img if torch.is_tensor(img) else np.asarray(img, dtype=np.uint8))
         shapes = {tuple(a.shape[:2]) for a in arrs}
         if len(shapes) == 1:
-            self.engine.set_frame_size(*shapes.pop())
-            return arrs
+            try:
+                self.engine.set_frame_size(*shapes.pop())
+                return arrs
+            except VitvsError:
+                # a geometry the fused resize cannot take (too many camera rows per patch for its LDS rows, or no memory for
+                # the staging buffers): the engine kept its previous geometry (vitvs_set_frame_size changes nothing on
+                # failure); fall back to the stand-alone resize launch below
+                pass
         self.engine.set_frame_size()
         return [self._resized(a) for a in arrs]
 
