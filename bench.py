@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent updates in flight per GPU (handles x streams, vit-vs_amd/pipeline.py); 0 = the measured "
                          "default 3; 1 = one stream, as in rounds 1-2")
+    ap.add_argument("--binned", action="store_true",
+                    help="3x3 log-binned descriptors (use_feature_binning: true, the reference's shipped default with "
+                         "--config vits14_308: config.yaml:17, vitvs_v2.py:482-493); the Gram's K becomes 9 D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode leg")
     ap.add_argument("--no-plain-chain", action="store_true",
@@ -341,6 +344,63 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     return best
 
 
+def overlapped_chain_us(prec, m, d, hidden, s_proj, s_fc2, dev, queues=3, blocks=12, reps=6, rounds=8):
+    """Per-launch time of the dominant GEMM symbol (the partial-sum kernel of proj and fc2) with `queues` queues busy — the regime
+    `value` is measured in, where a kernel's own duration is not defined (kernels of several queues share the chip) and the
+    instrumented pass therefore times it alone.  Each queue replays a captured chain of `reps` x `blocks` x [proj, fc2] launches
+    in forward order (12 weight sets, shared by the queues like the pipeline's one copy of the weights; activations and partial
+    sums per queue) on a high-priority stream of its own; the figure is wall time / launches over all queues (what
+    tools/op_chain `queues` reports), for `queues` queues and for one."""
+    import ctypes as C
+    import torch
+    from vitvs_amd import _lib
+    lib = _lib.load()
+    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32}[prec]
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[prec]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *shape: (torch.randn(shape, generator=g) * 0.05).to(dt).to(dev)   # noqa: E731  (random data: zeros run at a higher clock)
+    w_proj = [rnd(d, d) for _ in range(blocks)]
+    w_fc2 = [rnd(d, hidden) for _ in range(blocks)]
+    per_queue = []
+    for _ in range(queues):
+        per_queue.append(dict(a=rnd(m, d), h=rnd(m, hidden), part=torch.zeros((max(s_proj, s_fc2), m, d), dtype=torch.float32, device=dev),
+                              stream=torch.cuda.Stream(device=dev, priority=-1)))
+
+    def chain(q):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(reps):
+            for i in range(blocks):
+                lib.vitvs_op_linear_partial(code, C.c_void_p(q["a"].data_ptr()), C.c_void_p(w_proj[i].data_ptr()),
+                                            C.c_void_p(q["part"].data_ptr()), m, d, d, s_proj, st)
+                lib.vitvs_op_linear_partial(code, C.c_void_p(q["h"].data_ptr()), C.c_void_p(w_fc2[i].data_ptr()),
+                                            C.c_void_p(q["part"].data_ptr()), m, d, hidden, s_fc2, st)
+    for q in per_queue:
+        with torch.cuda.stream(q["stream"]):
+            chain(q)                                  # warm: LDS opt-in, code objects
+        q["stream"].synchronize()
+        q["graph"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(q["graph"], stream=q["stream"]):
+            chain(q)
+    launches = 2 * blocks * reps
+
+    def timed(n_q):
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _r in range(rounds):
+                for q in per_queue[:n_q]:
+                    with torch.cuda.stream(q["stream"]):
+                        q["graph"].replay()
+            for q in per_queue[:n_q]:
+                q["stream"].synchronize()
+            best = min(best, (time.perf_counter() - t0) * 1e6 / (rounds * launches * n_q))
+        return best
+    timed(queues)
+    return dict(queues=queues, per_launch_us=round(timed(queues), 3), per_launch_us_one_queue=round(timed(1), 3),
+                launches_per_queue_and_round=launches, rounds=rounds)
+
+
 # ----------------------------------------------------------------------------------------------- CPU oracle legs
 def cpu_model() -> str:
     try:
@@ -560,7 +620,7 @@ def run_rank(args):
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     cfg = config.baseline_config(args.config)
-    binned = False  # north_star path: token descriptors (binning is a tested option, not the headline)
+    binned = bool(args.binned)  # default: the north_star path's token descriptors; --binned: the reference's shipped default
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=binned)
     sd = weights.synthetic_state_dict(cfg, 0)
     B = args.pairs
@@ -737,6 +797,13 @@ def run_rank(args):
             plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_, in_flight), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
+        overlapped = None
+        if rank == 0 and world == 1 and not args.no_plain_chain and in_flight > 1:
+            m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
+            overlapped = overlapped_chain_us(args.precision, m_rows, cfg.dim, cfg.hidden, split_k(m_rows, cfg.dim, cfg.dim, bk_, in_flight),
+                                             split_k(m_rows, cfg.dim, cfg.hidden, bk_, in_flight), dev, queues=in_flight)
+        eng.lib.vitvs_op_plan_in_flight(1)              # the thread's hint back to its default: handles created below plan for themselves
+
         parity = None
         secondary = None
         if world == 1 and rank == 0 and not args.no_cpu_baseline and not dense:
@@ -802,7 +869,10 @@ def run_rank(args):
         import ctypes
         tile = (ctypes.c_int32 * 3)()
         prec_id = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16}[prec_tag]
-        if eng.lib.vitvs_op_linear_tile(prec_id, m, n, kk, s_ if partial else 0, tile) != 0:
+        prev_hint = eng.lib.vitvs_op_plan_in_flight(in_flight)       # the plan `value` ran under; restored at once
+        rc_ = eng.lib.vitvs_op_linear_tile(prec_id, m, n, kk, s_ if partial else 0, tile)
+        eng.lib.vitvs_op_plan_in_flight(prev_hint)
+        if rc_ != 0:
             return None
         if tile[2] == 0:
             return f"linear_big_kernel<{prec_tag},{tile[0]}x{tile[1]}>:" + ("BigPartial" if partial else "BigStore")
@@ -864,6 +934,18 @@ def run_rank(args):
             p_us = sum(plain[c] * kernels[c]["launches_per_step"] for c in members) / launches
             roof.update(plain_launch_us=round(p_us, 3), achieved_plain=round(fl / (p_us * 1e-6) / 1e12, 3),
                         frac_plain=round(fl / (p_us * 1e-6) / peak, 5))
+        if overlapped and dom == "linear_partial(proj+fc2)":
+            # ... and with `in_flight` queues busy, the regime `value` is measured in: proj and fc2 alternate 1 : 1 there, as in
+            # the forward (the patch-embedding launch, 1 of the symbol's 25 per update, is left out), so the FLOPs per launch
+            # are their mean
+            fl_o = (work["proj"][0] + work["fc2"][0]) / 2
+            o_us = overlapped["per_launch_us"]
+            overlapped.update(achieved=round(fl_o / (o_us * 1e-6) / 1e12, 3), unit="TFLOP/s", frac=round(fl_o / (o_us * 1e-6) / peak, 5),
+                              achieved_one_queue=round(fl_o / (overlapped["per_launch_us_one_queue"] * 1e-6) / 1e12, 3),
+                              algorithmic_flops_per_launch=fl_o,
+                              note="the dominant symbol as a captured chain of proj / fc2 launches in forward order on each of the "
+                                   "queues (random operands, 12 shared weight sets): wall time / launches over all queues")
+            roof["overlapped"] = overlapped
     else:
         roof = dict(kernel=symbol, classes=members, bound="hbm", achieved=round(by / avg_s / 1e9, 2), peak=PEAK_HBM / 1e9,
                     unit="GB/s", frac=round(by / avg_s / PEAK_HBM, 5), traffic=traffic, traffic_source=traffic_source,
@@ -880,11 +962,17 @@ def run_rank(args):
         config=dict(workload=f"{cfg.model_type} {cfg.img_size}x{cfg.img_size} frame pair(s): both frames forwarded "
                              f"through block {cfg.layer}, cosine correspondence, mutual-NN, {params.num_pairs} features "
                              f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update; "
+                             f"{'3x3 log-binned descriptors (9 D wide); ' if binned else ''}"
                              f"{B} pair(s) per update, {in_flight} independent update(s) in flight",
-                    key=args.config, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=in_flight, tokens=cfg.tokens, dim=cfg.dim,
+                    key=args.config, binned=binned, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=in_flight, tokens=cfg.tokens, dim=cfg.dim,
                     parallelism=(f"dp{world} (frame pairs sharded, v_c all-gather per step"
                                  f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
                     weights="synthetic seed 0", frame_seeds=seeds, selection="DENSE" if dense else "ORDER"),
+        protocol=(f"{in_flight} independent batch-{B} updates in flight per GPU (one handle + one high-priority stream each, shared "
+                  f"weights, hipGraph replay, the in_flight tile plan); the timed region is K updates between two barrier + "
+                  f"synchronize pairs, filling and draining the {in_flight} slots included" if in_flight > 1 else
+                  "one update in flight per GPU: one handle, one stream, plain launches"),
+        value_one_in_flight=(sequential["value"] if sequential else round(value, 2)),
         roofline=roof,
         cpu_baseline=None,
         parity=parity,

@@ -97,7 +97,7 @@ def test_closed_loop_raw_twist_equals_the_oracle_update_by_update():
         sim.apply_twist(lin, ang)
     print(f"closed loop fp32: {identical} of {n_updates} updates with arg-max tables identical to the oracle's "
           f"(draw, pixel features, raw and smoothed v_c then equal the oracle's)")
-    assert identical >= n_updates - 2
+    assert identical == n_updates                                       # deterministic fixture: measured 12 of 12
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

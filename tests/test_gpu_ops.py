@@ -395,3 +395,124 @@ def test_long_attention_deferred_rescale_with_slowly_growing_scores(lib, slope):
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all()
         assert _rel(out.cpu(), _attention_ref(q, 1, N, H)) <= tol
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The many-row selections of the "in_flight" hint (vitvs_set_option; kernels.h g_updates_in_flight): 256 x 256 tiles wherever they
+# divide from 1536 rows on (gemm_big.hip big_tile_width), at most two K slices and exactly two from 2048 rows on for the narrow
+# layers (gemm.hip splitk_slices), whole query blocks in the long-sequence attention (attention.hip attention_plan).  Row counts:
+# 4 / 8 ViT-B/16 pairs (1576 / 3152), ViT-B/8 448² (6274), ViT-L/14 518² (2740).
+@pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
+@pytest.mark.parametrize("M,N,K,gelu", [(1576, 2304, 768, 0), (1576, 3072, 768, 1), (3152, 2304, 768, 0), (3152, 3072, 768, 1),
+                                        (6274, 2304, 768, 0), (6274, 3072, 768, 1), (2740, 3072, 1024, 0), (2740, 4096, 1024, 1)])
+def test_linear_many_rows_under_the_in_flight_plan(lib, in_flight_plan, name, prec, dtype, tol, M, N, K, gelu):
+    t = (C.c_int32 * 3)()
+    assert lib.vitvs_op_linear_tile(prec, M, N, K, 0, t) == 0
+    assert (t[0], t[1], t[2]) == (256, 256, 0), f"the hint should select 256 x 256 tiles here, got {tuple(t)}"
+    lib.vitvs_op_plan_in_flight(1)
+    assert lib.vitvs_op_linear_tile(prec, M, N, K, 0, t) == 0
+    alone = tuple(t)
+    lib.vitvs_op_plan_in_flight(3)
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((N, K), g, K ** -0.5).to(dtype)
+    bias = _mk((N,), g, 0.1)
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    out = torch.full((M + 3, N), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_linear(prec, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(out), M, N, K, gelu, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all(), "rows beyond M were written"
+    assert _rel(out[:M].cpu(), ref) <= tol, f"(the alone plan's tile here: {alone})"
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
+@pytest.mark.parametrize("M,D,K,use_ls", [(1576, 768, 768, False), (1576, 768, 3072, False), (3152, 768, 768, False),
+                                          (3152, 768, 3072, False), (6274, 768, 768, False), (6274, 768, 3072, False),
+                                          (2740, 1024, 1024, True), (2740, 1024, 4096, True)])
+def test_split_k_pair_many_rows_under_the_in_flight_plan(lib, in_flight_plan, name, prec, dtype, tol, M, D, K, use_ls):
+    """proj / fc2 at many rows under the hint: the slice count the library picks there (at most 2 from 2048 rows on, where the alone
+    plan cuts 3 or 4; below that the many-row rule's 2 .. 4), the partial sums slice by slice, and residual_ln's sum + LayerNorm."""
+    slices = lib.vitvs_op_splitk_slices(prec, M, D, K)
+    lib.vitvs_op_plan_in_flight(1)
+    slices_alone = lib.vitvs_op_splitk_slices(prec, M, D, K)
+    lib.vitvs_op_plan_in_flight(3)
+    assert 1 <= slices <= (2 if M >= 2048 else 4) and slices <= slices_alone
+    g = torch.Generator().manual_seed(M + D + K)
+    A = _mk((M, K), g).to(dtype)
+    W = _mk((D, K), g, K ** -0.5).to(dtype)
+    bias = _mk((D,), g, 0.1)
+    ls = (1.0 + 0.3 * _mk((D,), g)) if use_ls else None
+    gamma, beta = 1.0 + 0.1 * _mk((D,), g), 0.1 * _mk((D,), g)
+    x0 = _mk((M, D), g)
+    upd = A.double() @ W.double().t() + bias.double()
+    if use_ls:
+        upd = upd * ls.double()
+    x_ref = x0.double() + upd
+    y_ref = torch.nn.functional.layer_norm(x_ref, (D,), gamma.double(), beta.double(), 1e-6)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    lsd = ls.cuda() if use_ls else None
+    x = x0.clone().cuda()
+    part = torch.full((slices, M, D), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.full((M, D), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_linear_partial(prec, _p(Ad), _p(Wd), _p(part), M, D, K, slices, _stream()) == 0
+    assert lib.vitvs_op_residual_ln(prec, _p(x), _p(part), slices, _p(bd), _p(lsd), _p(gamma.cuda()), _p(beta.cuda()), _p(out),
+                                    M, D, 1e-6, _stream()) == 0
+    torch.cuda.synchronize()
+    ks = K // slices
+    for z in range(slices):
+        ref_z = A[:, z * ks:(z + 1) * ks].double() @ W[:, z * ks:(z + 1) * ks].double().t()
+        assert _rel(part[z].cpu(), ref_z) <= 1e-3
+    assert _rel(x.cpu(), x_ref) <= 2e-6 + 1e-3
+    assert _rel(out.cpu(), y_ref) <= {_lib.BF16: 1e-2, _lib.F16: 2e-3}[prec]
+
+
+@pytest.mark.parametrize("name,prec,dtype,tol", [p for p in PRECS if p[0] != "fp32"])
+@pytest.mark.parametrize("n_img,N,H", [(2, 3137, 12), (2, 1370, 16), (1, 3026, 6), (16, 197, 12)])
+def test_attention_under_the_in_flight_plan(lib, in_flight_plan, name, prec, dtype, tol, n_img, N, H):
+    """Long sequences under the hint: whole query blocks per workgroup (no key ranges, no hand-off), with the forward's
+    pre-scaled q; against the fp64 softmax and bit for bit against the divided plan's merge order?  No: the divided plan sums
+    the same tiles in ranges, so the two agree to rounding only — asserted at the operator tolerance."""
+    g = torch.Generator().manual_seed(N * 3 + H)
+    D = H * 64
+    qkv = _mk((n_img * N, 3 * D), g).to(dtype)
+    qs = qkv.clone().float()
+    qs[:, :D] *= 0.125 * 1.4426950408889634
+    qs = qs.to(dtype)
+    t = qs.double().clone()
+    t[:, :D] /= 0.125 * 1.4426950408889634
+    ref = _attention_ref(t, n_img, N, H)
+    qd = qs.cuda()
+    out = torch.full((n_img * N, D), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_attention_q(prec, _p(qd), _p(out), n_img, N, H, 1, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    bar = {_lib.BF16: 2e-2, _lib.F16: 3e-3}[prec]
+    assert _rel(out.cpu(), ref) <= bar
+    lib.vitvs_op_plan_in_flight(1)
+    out1 = torch.full((n_img * N, D), float("nan"), dtype=dtype, device="cuda")
+    assert lib.vitvs_op_attention_q(prec, _p(qd), _p(out1), n_img, N, H, 1, _stream()) == 0
+    torch.cuda.synchronize()
+    lib.vitvs_op_plan_in_flight(3)
+    assert _rel(out1.cpu(), ref) <= bar and _rel(out.cpu(), out1.cpu()) <= bar
+
+
+def test_a_16bit_many_token_handle_created_under_a_thread_hint_still_runs_alone(lib):
+    """vitvs_create sizes the key-split attention workspace for the ALONE plan whatever vitvs_op_plan_in_flight left on the
+    calling thread: a bf16 ViT-B/8 448² handle created under hint 3 and then used with its own in_flight = 1 must
+    find its states and tickets (it used to fail every forward with -3)."""
+    import numpy as np
+    from vitvs_amd import config, synth, weights
+    from vitvs_amd.engine import Engine
+    prev = lib.vitvs_op_plan_in_flight(3)
+    try:
+        cfg = config.baseline_config("vitb8_448")
+        eng = Engine(cfg, config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False), precision="bf16", max_pairs=1)
+    finally:
+        lib.vitvs_op_plan_in_flight(prev)
+    eng.load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    toks = eng.forward_tokens(synth.frame_pair(cfg.img_size, 3)[0][None])
+    torch.cuda.synchronize()
+    assert torch.isfinite(toks).all() and np.isfinite(float(toks.abs().max()))
+    eng.close()

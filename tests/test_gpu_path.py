@@ -42,6 +42,80 @@ def _oracle_tokens(cfg, sd, frames):
                                 mean=cfg.mean, std=cfg.std)
 
 
+_PAIR_TOKENS = {}
+
+
+def _oracle_pair_tokens(key, weight_seed, frame_seed):
+    """Oracle patch tokens of the (desired, current) pair of a baseline config with synthetic weights, memoised: the same pair is
+    checked under several tile plans and precisions, the CPU forward runs once."""
+    k = (key, int(weight_seed), int(frame_seed))
+    if k not in _PAIR_TOKENS:
+        cfg = config.baseline_config(key)
+        sd = weights.synthetic_state_dict(cfg, int(weight_seed))
+        des, cur = synth.frame_pair(cfg.img_size, int(frame_seed))
+        _PAIR_TOKENS[k] = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+    return _PAIR_TOKENS[k]
+
+
+# The tile plans an update can run under (include/vitvs.h "several updates in flight"):
+#   alone           one handle, the one-stream plan (8-wave GEMM workgroups, 3 K slices, key-split long attention, balanced many-row tiles)
+#   in_flight3      the same handle with the "in_flight" hint: 4-wave workgroups, two K slices on the XCD-mapped grid, whole-item
+#                   attention, 256 x 256 many-row tiles, two slices from 2048 rows on — the plan bench.py measures `value` with
+#   busy_pipeline   that plan through vit-vs_amd/pipeline.py, the way `value` is measured: three handles on three high-priority
+#                   streams sharing one copy of the weights, hipGraph replay per slot; the update under test is the third of five
+#                   identical submissions, so both other slots run beside it, and all five must agree bit for bit
+PLANS = ["alone", "in_flight3", "busy_pipeline"]
+
+
+class _PlanRunner:
+    def __init__(self, plan, cfg, params, sd, precision, max_pairs=1, max_rows=None, binned=None):
+        self.plan, self.pipe = plan, None
+        if plan == "busy_pipeline":
+            from vitvs_amd.pipeline import UpdatePipeline
+            assert binned is None or binned == params.use_feature_binning
+            self.pipe = UpdatePipeline(cfg, params, sd, precision=precision, depth=3, max_pairs=max_pairs, max_rows=max_rows)
+            self.eng = self.pipe.engines[2]
+        else:
+            self.eng = _engine(cfg, params, precision=precision, max_pairs=max_pairs, max_rows=max_rows, binned=binned).load_state_dict(sd)
+            if plan == "in_flight3":
+                self.eng.set_option("in_flight", 3)
+
+    def compute_velocity(self, cur, des, Z, K, mode=_lib.SELECT_DENSE, selection=None, des_shared=False, num_pairs=None):
+        if self.pipe is None:
+            return self.eng.compute_velocity(cur, des, Z, K, mode=mode, selection=selection, des_shared=des_shared,
+                                             num_pairs=num_pairs)
+        e = self.eng
+        cur_t, des_t = e._frames(cur), e._frames(des)
+        n = cur_t.shape[0]
+        z = torch.as_tensor(Z).reshape(n, e.params.v_max, e.params.u_max).to(e.device).contiguous()
+        kk = torch.as_tensor(K, dtype=torch.float64).reshape(-1, 4)
+        kk = (kk.expand(n, 4) if kk.shape[0] == 1 and n > 1 else kk).contiguous().to(e.device)
+        k = e._num_pairs(num_pairs)
+        sel, cnt = e._selection_args(mode, selection, n, e.tokens, k)
+        tickets = [self.pipe.submit(cur_t, des_t, z, kk, mode, sel, cnt, des_shared, k) for _ in range(5)]
+        self.eng = self.pipe.engines[tickets[2] % 3]            # its detail buffers: tickets 3 and 4 run on the two other slots
+        v, st = self.pipe.result(tickets[2])
+        self.pipe.synchronize()
+        for t in tickets[3:]:                                   # the neighbours computed the same update: same bits
+            v_n, st_n = self.pipe.result(t)
+            assert torch.equal(v_n, v) and torch.equal(st_n, st), "slots of one pipeline disagree on the same update"
+        return v, st
+
+    def last_details(self, n=1):
+        return self.eng.last_details(n)
+
+    def extract_descriptors(self, frames):
+        if self.pipe is not None:
+            self.pipe.synchronize()
+        return self.eng.extract_descriptors(frames)
+
+    def close(self):
+        if self.pipe is not None:
+            self.pipe.close()
+        else:
+            self.eng.close()
+
+
 # ----------------------------------------------------------------------------- forward
 @pytest.mark.parametrize("layerscale", [False, True])
 def test_forward_tokens_tiny_fp32(layerscale):
@@ -234,24 +308,27 @@ def test_pinv_rank_deficient_matches_numpy():
 
 
 # ----------------------------------------------------------------------------- end to end
-def _e2e(key, tag, precision):
+def _e2e(key, tag, precision, plan="alone"):
     blob = load_golden(f"e2e_{key}.npz")
     case = golden_case(blob, tag)
     cfg = config.baseline_config(key)
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=(tag == "binned"))
-    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    eng = _PlanRunner(plan, cfg, params, sd, precision)
     sel = _ids(case["points1"], cfg.grid)
     v, st = eng.compute_velocity(cur, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_EXPLICIT,
                                  selection=[sel])
-    return case, eng.last_details(1), v.cpu().numpy()[0], int(st[0])
+    out = case, eng.last_details(1), v.cpu().numpy()[0].copy(), int(st[0])
+    eng.close()
+    return out
 
 
+@pytest.mark.parametrize("plan", PLANS)
 @pytest.mark.parametrize("key,tag", [("vits16_224", "plain"), ("vits16_224", "binned"), ("vitb16_224", "plain"),
                                      ("vitb16_224", "binned"), ("vits14_308", "binned")])
-def test_compute_velocity_fp32_matches_reference(key, tag):
-    case, det, v, st = _e2e(key, tag, "fp32")
+def test_compute_velocity_fp32_matches_reference(key, tag, plan):
+    case, det, v, st = _e2e(key, tag, "fp32", plan)
     assert bool(case["strict"])
     assert st == 0
     assert np.array_equal(det["nn_1"][0], case["nn_1"])   # bit-exact argmax correspondences
@@ -379,7 +456,9 @@ def test_compute_velocity_fp32_many_tokens(key):
 #   * the ORDER selection is exact given the device's own tables (first num_pairs mutual NNs met in the visiting order), and
 #     `same_draw` counts the pairs whose draw and matches equal the ones the fp32 oracle's tables give.
 # DESIGN.md §3 quotes these numbers; they are assertions here.
-MODE_BARS = {"bf16": dict(agree1=0.99, agree2=0.99, tie=2e-2, sim_atol=2e-2, same_fixture=8, same_draw=7),
+# bf16: at most ONE token of a pair's 196 flips across a near-tie, in either table (measured per-pair minimum 0.9949 = 195 / 196 on
+# every plan: nn_1 mean 0.9981 on all three; nn_2 none alone, one of pair 4's under the in-flight plan); fp16: none
+MODE_BARS = {"bf16": dict(agree1=195 / 196, agree2=195 / 196, tie=2e-2, sim_atol=2e-2, same_fixture=8, same_draw=8),
              "fp16": dict(agree1=1.0, agree2=1.0, tie=3e-3, sim_atol=3e-3, same_fixture=8, same_draw=8)}
 
 
@@ -400,13 +479,14 @@ def _first_mutual_in_order(order, nn1, nn2, k):
     return np.array([x for x in order if mutual[x]][:k], dtype=np.int64)
 
 
+@pytest.mark.parametrize("plan", PLANS)
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_16bit_modes_over_8_accepted_pairs(precision):
+def test_16bit_modes_over_8_accepted_pairs(precision, plan):
     blob = load_golden("rig8_vitb16_224.npz")
     cfg = config.baseline_config("vitb16_224")
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    eng = _PlanRunner(plan, cfg, params, sd, precision)
     depth = synth.depth_pattern()
     g, t, k = cfg.grid, cfg.tokens, params.num_pairs
     bars = MODE_BARS[precision]
@@ -414,7 +494,7 @@ def test_16bit_modes_over_8_accepted_pairs(precision):
     for i, seed in enumerate(int(x) for x in blob["frame_seeds"]):
         case = golden_case(blob, f"pair{i}")
         des, cur = synth.frame_pair(cfg.img_size, seed)
-        toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+        toks = _oracle_pair_tokens("vitb16_224", blob["weight_seed"], seed)
         S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
         n1r, n2r = case["nn_1"].astype(np.int64), case["nn_2"].astype(np.int64)
         # (1) the reference's own draw (fixture), EXPLICIT selection
@@ -447,10 +527,40 @@ def test_16bit_modes_over_8_accepted_pairs(precision):
         assert _rel_l2(v2.cpu().numpy()[0], _law_on(cfg, params, want_sel, d1[want_sel], depth, k)["v_c"]) <= 1e-9 <= VC_TOL
         ref_sel = _first_mutual_in_order(order, n1r, n2r, k)
         same_draw += int(np.array_equal(ref_sel, want_sel) and np.array_equal(d1[want_sel], n1r[ref_sel]))
-    print(f"{precision}: arg-max agreement with the fp32 oracle over 8 pairs: nn_1 mean {np.mean(agree1):.4f} min {min(agree1):.4f}, "
+    eng.close()
+    print(f"{precision} [{plan}]: arg-max agreement with the fp32 oracle over 8 pairs: nn_1 mean {np.mean(agree1):.4f} min {min(agree1):.4f}, "
           f"nn_2 mean {np.mean(agree2):.4f} min {min(agree2):.4f}; v_c <= 1e-9 on 8/8 pairs in both selections; the fixture's "
           f"matches at the fixture's draw on {same_fixture}/8, the oracle tables' ORDER draw on {same_draw}/8")
     assert same_fixture >= bars["same_fixture"] and same_draw >= bars["same_draw"]
+
+
+# The reference's SHIPPED configuration (config.yaml:1-17: DINOv2 ViT-S/14 at 308², use_feature_binning: true -> 9 x 384 = 3456-wide
+# descriptors, vitvs_v2.py:482-493, dinov2_extractor.py:265-311) in the 16-bit modes, under every tile plan.  Bars as measured.
+BINNED16 = {"bf16": dict(tie=2e-2, agree=0.97), "fp16": dict(tie=3e-3, agree=0.995)}
+
+
+@pytest.mark.parametrize("plan", PLANS)
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_16bit_binned_reference_default_config(precision, plan):
+    key, bars = "vits14_308", BINNED16[precision]
+    case, det, v, st = _e2e(key, "binned", precision, plan)
+    blob = load_golden(f"e2e_{key}.npz")
+    cfg = config.baseline_config(key)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=True)
+    toks = _oracle_pair_tokens(key, blob["weight_seed"], blob["frame_seed"])
+    binned = vit_ref.log_bin(toks, cfg.grid)
+    S = sr.cosine_matrix(binned[0], binned[1], exact_order=False).numpy()
+    assert np.array_equal(S.argmax(1), case["nn_1"]) and np.array_equal(S.argmax(0), case["nn_2"])   # the fixture IS this oracle
+    a1 = _tie_tolerant_agreement(det["nn_1"][0], case["nn_1"], S, bars["tie"])
+    a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, bars["tie"])
+    print(f"{key} binned {precision} [{plan}]: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f}")
+    assert st == 0 and a1 >= bars["agree"] and a2 >= bars["agree"]
+    np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=bars["tie"])
+    sel = _ids(case["points1"], cfg.grid)
+    dev_matches = det["nn_1"][0].astype(np.int64)[sel]
+    want = case["v_c"] if np.array_equal(dev_matches, case["nn_1"].astype(np.int64)[sel]) else \
+        _law_on(cfg, params, sel, dev_matches, synth.depth_pattern(), params.num_pairs)["v_c"]
+    assert _rel_l2(v, want) <= 1e-9 <= VC_TOL
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -561,6 +671,100 @@ def test_forward_tokens_with_trained_like_statistics(precision):
     assert torch.isfinite(got).all() and float(per_chan.max()) <= bar_err and float(cos.min()) >= bar_cos
 
 
+# Trained-like statistics END TO END (weights.trained_like_state_dict: peaky softmax rows, four "massive activation" residual
+# channels — what the reference's pretrained checkpoints look like, dinov2_extractor.py:65-83; every other e2e fixture is
+# trunc-normal(0.02)).  The question the token-level stress test above leaves open: what do the 16-bit forwards' token errors do
+# to the arg-max tables and to v_c?  Per (config, precision, plan), asserted at the measured values (profiles/r04_notes.md):
+#   sim_err     max |S_device - S_oracle| (S_device: exact fp64 Gram of the device's own descriptors): the mode's similarity error
+#   agree       share of tokens whose arg-max is the oracle's, the smaller of the two tables
+#   gap         the largest amount by which a differing device arg-max falls short of the oracle's maximum IN THE ORACLE'S MATRIX
+#               (0 for identical tables; a disagreement can only be a pair of candidates closer than 2 sim_err there, asserted)
+#   drawn_same  share of the 24 drawn features that are the oracle's draw with the oracle's match
+# v_c is the oracle's law on the device's own draw to 1e-9 in every mode (never skipped), and the oracle's v_c itself where the
+# device's tables are the oracle's (fp32: asserted).  What it shows: with four channels 60 x the median the cosine is dominated by
+# those channels (95 % of a token's squared norm), similarities crowd into [0.90, 0.99] with a median top-1 / top-2 margin of
+# 3e-3 ... 7e-3.  The 16-bit forwards' logit errors (|q . k| of tens of units x 2^-8 operand rounding, amplified by the exponential)
+# move the tokens by degrees: fp16 keeps 96 - 99.5 % of the arg-maxes (every miss within 5e-3 of the oracle's maximum), bf16 — 8 x
+# coarser operands — 77 - 91 %, with misses up to 0.2 away.  On weights like these fp16 (same kernels, same speed) is the throughput
+# dtype to use; bf16's 99.8 % on the trunc-normal fixtures does not carry over.
+TRAINED_E2E = {   # measured (alone / in_flight3), MI355X:      sim_err            agree (min of nn_1, nn_2)   gap                drawn_same
+    ("vitb16_224", "fp32"): dict(sim_err=1e-4, agree=1.0, gap=0.0, drawn_same=1.0),      # 2.8e-5 / 2.7e-5   1.0000                      0                  1.00
+    ("vitb16_224", "fp16"): dict(sim_err=5e-2, agree=0.985, gap=1e-3, drawn_same=0.95),  # 3.2e-2 / 2.9e-2   0.9898                      2.8e-4             0.96
+    ("vitb16_224", "bf16"): dict(sim_err=0.35, agree=0.88, gap=0.25, drawn_same=0.85),   # 2.7e-1 / 2.9e-1   0.9082 / 0.8980             2.2e-1             0.88
+    ("vitl14_518", "fp32"): dict(sim_err=2e-4, agree=1.0, gap=0.0, drawn_same=1.0),      # 7.4e-5            1.0000                      0                  1.00
+    ("vitl14_518", "fp16"): dict(sim_err=6e-2, agree=0.95, gap=1e-2, drawn_same=0.95),   # 4.1e-2            0.9591 / 0.9613             4.5e-3 / 3.3e-3    1.00 / 0.96
+    ("vitl14_518", "bf16"): dict(sim_err=0.35, agree=0.75, gap=0.10, drawn_same=0.60),   # 2.9e-1 / 3.1e-1   0.7714 / 0.7736             7.9e-2             0.71 / 0.67
+}
+_TRAINED_ORACLE = {}
+
+
+def _trained_like_oracle(key):
+    if key not in _TRAINED_ORACLE:
+        cfg = config.baseline_config(key)
+        sd = weights.trained_like_state_dict(cfg, 3)
+        des, cur = synth.frame_pair(cfg.img_size, synth.RIG8_FRAME_SEEDS[0] if key == "vitb16_224" else synth.ACCEPTED_FRAME_SEEDS[key])
+        toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+        S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
+        _TRAINED_ORACLE[key] = (cfg, sd, des, cur, S)
+    return _TRAINED_ORACLE[key]
+
+
+def _oracle_gap(got, ref_idx, S_rows):
+    """(agreement, the largest shortfall of a differing choice against the oracle's maximum, in the oracle's matrix)"""
+    bad = np.nonzero(got != ref_idx)[0]
+    gap = float(max((S_rows[i, ref_idx[i]] - S_rows[i, got[i]] for i in bad), default=0.0))
+    return 1.0 - len(bad) / len(ref_idx), gap
+
+
+@pytest.mark.parametrize("plan", ["alone", "in_flight3"])
+@pytest.mark.parametrize("key,precision", list(TRAINED_E2E))
+def test_trained_like_statistics_end_to_end(key, precision, plan):
+    bars = TRAINED_E2E[(key, precision)]
+    cfg, sd, des, cur, S = _trained_like_oracle(key)
+    t = cfg.tokens
+    n1r, n2r = S.argmax(1), S.argmax(0)
+    mutual_ref = int((n2r[n1r] == np.arange(t)).sum())
+    top2 = np.sort(S, axis=1)[:, -2:]
+    margins = top2[:, 1] - top2[:, 0]
+    assert 4 <= mutual_ref < t and float(S.max(1).mean()) <= 0.99            # SURVEY §8(d)'s acceptance rule minus the margin clause
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    eng = _PlanRunner(plan, cfg, params, sd, precision)
+    depth = synth.depth_pattern()
+    k = params.num_pairs
+    order = np.random.default_rng(77).permutation(t).astype(np.int32)
+    v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order[None])
+    det = eng.last_details(1)
+    v = v.cpu().numpy()[0].copy()
+    d1, d2 = det["nn_1"][0].astype(np.int64), det["nn_2"][0].astype(np.int64)
+    assert int(st[0]) == 0
+    # the device's similarity matrix from the device's own descriptors (exact Gram): the mode's similarity error on these weights
+    d = eng.extract_descriptors(np.stack([des, cur])).double().cpu()[:, 0]
+    dn = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    S_dev = (dn[0] @ dn[1].T).numpy()
+    for got, M in ((d1, S_dev), (d2, S_dev.T)):                                # the device's tables ARE the arg-maxes of its own matrix
+        assert float((M.max(1) - M[np.arange(t), got]).max()) <= 1e-6
+    sim_err = float(np.abs(S_dev - S).max())
+    a1, g1 = _oracle_gap(d1, n1r, S)
+    a2, g2 = _oracle_gap(d2, n2r, S.T)
+    # the draw: exact given the device's tables; the law on it
+    want_sel = _first_mutual_in_order(order, d1, d2, k)
+    assert len(want_sel) == k and np.array_equal(det["selected"][0, :k].astype(np.int64), want_sel)
+    assert _rel_l2(v, _law_on(cfg, params, want_sel, d1[want_sel], depth, k)["v_c"]) <= 1e-9 <= VC_TOL
+    ref_sel = _first_mutual_in_order(order, n1r, n2r, k)
+    v_ref = _law_on(cfg, params, ref_sel, n1r[ref_sel], depth, k)["v_c"]
+    drawn_same = float(np.mean([(x in set(ref_sel.tolist())) and d1[x] == n1r[x] for x in want_sel]))
+    mutual_dev = int((d2[d1] == np.arange(t)).sum())
+    print(f"trained-like {key} {precision} [{plan}]: oracle margins median {np.median(margins):.2e} min {margins.min():.2e}, "
+          f"{mutual_ref} mutual NNs (device {mutual_dev}); max |S_device - S_oracle| {sim_err:.2e}; arg-max agreement nn_1 {a1:.4f} "
+          f"nn_2 {a2:.4f}, largest oracle gap of a differing choice {max(g1, g2):.2e}; {drawn_same:.2f} of the {k} drawn features are "
+          f"the oracle's (token and match); v_c vs the oracle's v_c under the same visiting order: rel-L2 {_rel_l2(v, v_ref):.2e}")
+    eng.close()
+    assert sim_err <= bars["sim_err"] and max(g1, g2) <= min(bars["gap"], 2 * sim_err + 1e-6)
+    assert min(a1, a2) >= bars["agree"] and drawn_same >= bars["drawn_same"]
+    if np.array_equal(d1, n1r) and np.array_equal(d2, n2r):
+        assert _rel_l2(v, v_ref) <= 1e-9
+
+
 # BASELINE.json configs[4] (fp16 DINOv2 ViT-L/14 518², 1369 tokens) and configs[2] in the throughput dtype (bf16 DINO ViT-B/8
 # 448², 3136 tokens), END TO END in their own dtype: these are the sizes where the 16-bit modes take the Gram on the f16
 # matrix cores from a hi / lo split of the descriptors (correspond.hip), the 256-row GEMM tiles and the key-split attention.
@@ -568,8 +772,9 @@ def test_forward_tokens_with_trained_like_statistics(precision):
 FULL16 = {("vitl14_518", "fp16"): dict(tie=1e-3, agree=0.995), ("vitb8_448", "bf16"): dict(tie=5e-3, agree=0.985)}
 
 
+@pytest.mark.parametrize("plan", PLANS)
 @pytest.mark.parametrize("key,precision", list(FULL16))
-def test_compute_velocity_16bit_many_tokens_full_size(key, precision):
+def test_compute_velocity_16bit_many_tokens_full_size(key, precision, plan):
     """(a) the device's arg-max tables are maxima of an fp64 Gram of the device's OWN descriptors up to 1e-6 ties (the f16
     split Gram loses nothing that matters); (b) against the fp32 oracle every disagreement is a near-tie of the oracle's
     similarity matrix at the mode's similarity error (top-1 / top-2 margins at thousands of tokens are ~1e-6, so the tables
@@ -581,7 +786,7 @@ def test_compute_velocity_16bit_many_tokens_full_size(key, precision):
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
+    eng = _PlanRunner(plan, cfg, params, sd, precision)      # in_flight3 / busy_pipeline: whole-item attention, 256 x 256 tiles, two slices
     depth = synth.depth_pattern()
     t, k = cfg.tokens, params.num_pairs
     order = np.random.default_rng(31).permutation(t).astype(np.int32)
@@ -598,12 +803,13 @@ def test_compute_velocity_16bit_many_tokens_full_size(key, precision):
         assert float((M.max(1) - M[np.arange(t), got]).max()) <= 1e-6, "an arg-max of the device Gram is not a maximum of the exact Gram"
     np.testing.assert_allclose(det["sim_1"][0], S_dev.max(1), rtol=0, atol=2e-6)
     # (b) the fp32 oracle
-    toks = _oracle_tokens(cfg, sd, np.stack([des, cur]))[:, 1:]
+    toks = _oracle_pair_tokens(key, blob["weight_seed"], blob["frame_seed"])
     S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
     a1 = _tie_tolerant_agreement(d1, S.argmax(1), S, bars["tie"])
     a2 = _tie_tolerant_agreement(d2, S.argmax(0), S.T, bars["tie"])
     desc_err = float(np.abs(S_dev - S).max())
-    print(f"{key} {precision}: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f} (every disagreement a tie "
+    eng.close()
+    print(f"{key} {precision} [{plan}]: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f} (every disagreement a tie "
           f"<= {bars['tie']}); max |S_device - S_oracle| = {desc_err:.3e}")
     assert a1 >= bars["agree"] and a2 >= bars["agree"] and desc_err <= bars["tie"]
     # (c) the draw and the law
@@ -634,7 +840,8 @@ def test_batched_pairs_and_shared_goal():
     assert torch.equal(vs, vr) and torch.equal(ss, sr_)
 
 
-def test_rig_of_8_vitb16_pairs_in_one_call():
+@pytest.mark.parametrize("plan", PLANS)
+def test_rig_of_8_vitb16_pairs_in_one_call(plan):
     """BASELINE.json configs[3] on one GPU: 8 ViT-B/16 224² pairs in ONE call (what one rank of the rig runs when the
     rig is smaller than the camera count).  Against the reference-generated fixture: arg-max tables bit-exact and v_c
     <= 1e-9 for every pair given the reference's draw (pair 0 is the headline fixture's pair); against 8 single calls:
@@ -650,7 +857,7 @@ def test_rig_of_8_vitb16_pairs_in_one_call():
     cur = np.stack([p[1] for p in pairs])
     depth = np.stack([synth.depth_pattern()] * 8)
     sels = [_ids(blob[f"pair{i}/points1"], cfg.grid) for i in range(8)]
-    eng = _engine(cfg, params, precision="fp32", max_pairs=8).load_state_dict(sd)
+    eng = _PlanRunner(plan, cfg, params, sd, "fp32", max_pairs=8)
     vb, sb = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=sels)
     detb = eng.last_details(8)
     vb = vb.cpu().numpy()

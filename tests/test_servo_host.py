@@ -101,3 +101,79 @@ def test_shipped_reference_config_gives_the_package_defaults():
     rc = config.load_reference_config(shipped)
     assert rc.servo == config.ServoParams()
     assert rc.max_iterations == 1500 and rc.max_velocity_vector_history == 200
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# servo.MultiController's bookkeeping on CPU (a stand-in engine; the device path is tests/test_gpu_multi.py)
+class _ScriptedEngine:
+    """Batched stand-in for Engine: the twist of camera frame f is a function of the frame's first pixel, status from its second."""
+    max_pairs, tokens, max_rows = 8, 16, 48
+    device = torch.device("cpu")
+
+    class cfg:
+        img_size = 8
+
+    def __init__(self, params):
+        self.params = params
+        self.calls = []
+
+    def set_frame_size(self, *a):
+        return self
+
+    def compute_velocity(self, cur, des, z, K, mode=None, selection=None, des_shared=False, num_pairs=None):
+        n = cur.shape[0]
+        self.calls.append(dict(n=n, mode=mode, selection=selection, num_pairs=num_pairs, z=np.asarray(z).copy()))
+        v = torch.stack([torch.full((6,), float(cur[j, 0, 0, 0]) + 0.25 * float(des[j, 0, 0, 0]), dtype=torch.float64) for j in range(n)])
+        st = torch.tensor([int(cur[j, 0, 0, 1]) for j in range(n)], dtype=torch.int32)
+        return v, st
+
+
+def test_multi_controller_keeps_every_cameras_state_apart():
+    from vitvs_amd import _lib, config
+    params = config.ServoParams(dino_input_size=8, use_feature_binning=False)
+    eng = _ScriptedEngine(params)
+    frame = lambda a, status=0: np.full((8, 8, 3), 0, np.uint8) + np.array([a, status, 0], np.uint8)   # noqa: E731
+    goals = [frame(4 * c) for c in range(3)]
+    mc = servo.MultiController(eng, goals, selection="order", generator=torch.Generator().manual_seed(2))
+    depth = np.ones((params.v_max, params.u_max), np.uint16)
+    # round 1: camera 0 fine, camera 1 reports no correspondence, camera 2 has no image yet
+    mc.image_callback_rgb(0, frame(10)); mc.image_callback_depth(0, depth)
+    mc.image_callback_rgb(1, frame(20, _lib.STATUS_NO_CORRESPONDENCE)); mc.image_callback_depth(1, depth)
+    mc.ibvs()
+    call = eng.calls[-1]
+    assert call["n"] == 2 and call["mode"] == _lib.SELECT_ORDER and call["selection"].shape == (2, eng.tokens)
+    assert sorted(call["selection"][0].tolist()) == list(range(eng.tokens))          # a permutation per camera
+    assert not torch.equal(call["selection"][0], call["selection"][1])
+    assert np.array_equal(mc.cameras[0].v_c, np.full(6, 10.0)) and mc.cameras[0].feature_failure_count == 0   # EMA: first sample
+    assert mc.cameras[1].v_c is None and mc.cameras[1].feature_failure_count == 1 and mc.cameras[1].last_status == 1
+    assert mc.cameras[2].v_c is None and mc.cameras[2].last_status is None
+    # round 2: camera 0 again (EMA advances), camera 1 recovers (counter back to 0), camera 2 arrives without depth
+    mc.image_callback_rgb(0, frame(30))
+    mc.image_callback_rgb(1, frame(40))
+    mc.image_callback_rgb(2, frame(50))
+    mc.ibvs()
+    a = params.ema_alpha
+    assert np.allclose(mc.cameras[0].v_c, a * 30.0 + (1 - a) * 10.0, rtol=0, atol=1e-15)
+    assert np.array_equal(mc.cameras[1].v_c, np.full(6, 40.0 + 0.25 * 4)) and mc.cameras[1].feature_failure_count == 0
+    assert mc.cameras[2].v_c is None and mc.cameras[2].last_status == 0               # "Failed to get depth - skipping": v_c stays unset
+    assert eng.calls[-1]["n"] == 3 and not eng.calls[-1]["z"][2].any()                # a dummy depth image went in for camera 2
+    assert len(mc.cameras[0].velocity_vector_history) == 2 and len(mc.cameras[1].velocity_vector_history) == 1
+    assert mc.v_c[2] is None and mc.publish_twist(0) == servo.twist_from_velocity(mc.cameras[0].v_c, params.max_velocity)
+    # the 10th consecutive failure of ONE camera raises the reference's error; the others' counters are untouched
+    for _ in range(8):
+        mc.image_callback_rgb(1, frame(20, _lib.STATUS_NO_CORRESPONDENCE))
+        mc.ibvs()
+    assert mc.cameras[1].feature_failure_count == 8
+    mc.ibvs()
+    with pytest.raises(RuntimeError, match="Persistent feature detection failure"):
+        mc.ibvs()
+    assert mc.cameras[0].feature_failure_count == 0
+    # explicit ids per round
+    mc2 = servo.MultiController(eng, goals[:2])
+    mc2.image_callback_rgb(0, frame(1)); mc2.image_callback_rgb(1, frame(2))
+    mc2.ibvs(selection=[[1, 2, 3, 4], [5, 6, 7, 8]])
+    assert eng.calls[-1]["mode"] == _lib.SELECT_EXPLICIT and [list(s) for s in eng.calls[-1]["selection"]] == [[1, 2, 3, 4], [5, 6, 7, 8]]
+    with pytest.raises(ValueError):
+        servo.MultiController(eng, goals, selection="reference")
+    with pytest.raises(ValueError):
+        servo.MultiController(eng, [frame(0)] * 9)

@@ -918,7 +918,7 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
     for (auto& g : h->graphs)
         if (g.key == key) ge = &g;
     if (!ge) {
-        if (h->graphs.size() >= 8) {  // evict the least recently used entry
+        if (h->graphs.size() >= 32) {  // evict the least recently used entry (8 cameras sharing a pipeline slot = 8 keys)
             size_t victim = 0;
             for (size_t i = 1; i < h->graphs.size(); ++i)
                 if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;

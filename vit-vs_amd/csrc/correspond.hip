@@ -12,23 +12,59 @@
 //   S * 2^20 = hi1.hi2 + hi1.lo2 + lo1.hi2      (the dropped lo1.lo2 term is < 2^-22 relative)
 // as ONE contraction over 3 D: desired rows are stored [hi | hi | lo], current rows [hi | lo | hi] (split_desc_kernel).
 // ViT-B/8 448² (3136 tokens): 156 us -> see profiles/r02_notes.md.
+#include <algorithm>
+
 #include "gemm_core.h"
 #include "kernels.h"
 
 namespace vitvs {
 
+// Tile order.  A tile of the Gram reads one BM-row panel of the desired descriptors and one BN-row panel of the current ones, both
+// over the whole contraction; panels are shared only through the XCD's private L2 (4 MB, not coherent with the other seven), and a
+// workgroup with linear id i runs on XCD i % 8.  The plain (column, row) grid therefore put every panel on all eight XCDs:
+// 313.8 MB fetched for 28.9 MB of split descriptors at 3136 tokens (10.9 x; profiles/r03_pmc_traffic_vitb8_448.json), 8.7 MB for
+// 1.2 MB at 196 tokens.  Here the tiles are listed band by band (a band = `hb` row panels over all column panels, walked column
+// by column, the band's rows fastest) and XCD x — workgroup ids x, x + 8, ... — takes the x-th eighth of that list, balanced to
+// one tile: the tiles resident on an XCD at any time share a column panel `hb` ways and the band's `hb` row panels among all of
+// them.  hb ~ sqrt(tiles / 8) makes an XCD's share square; with square shares the eight L2s cannot fetch less than sqrt(8) = 2.83 x
+// the operands (each needs T / sqrt(8) rows of both frames).
+struct GramMap { int i0, j0; bool valid; };
+template <int BM, int BN>
+__device__ __forceinline__ GramMap gram_tile(int T, int hb) {
+    const int ty = (T + BM - 1) / BM, tx = (T + BN - 1) / BN, tiles = ty * tx;
+    const int per = (tiles + 7) >> 3;
+    const int local = (int)(blockIdx.x >> 3), t = (int)(blockIdx.x & 7) * per + local;
+    if (local >= per || t >= tiles) return GramMap{0, 0, false};
+    const int band = t / (hb * tx), rem = t - band * hb * tx;
+    const int rows = min(hb, ty - band * hb);                  // the last band may be lower
+    const int c = rem / rows, r = rem - c * rows;
+    return GramMap{(band * hb + r) * BM, c * BN, true};
+}
+// host side: band height and workgroups per XCD
+static int gram_band_rows(int T, int BM, int BN, int* per_xcd) {
+    const int ty = (T + BM - 1) / BM, tx = (T + BN - 1) / BN;
+    const int per = (ty * tx + 7) / 8;
+    *per_xcd = per;
+    int hb = 1;
+    while ((hb + 1) * (hb + 1) <= per) ++hb;                    // floor(sqrt(per))
+    if (hb * (hb + 1) <= per) ++hb;                             // round to nearest
+    return std::min(hb, ty);
+}
+
 // E: float (Dp = descriptor length, scale 1) or f16 (Dp = 3 x descriptor length of the split rows, scale 2^-20)
 template <typename E, int BM, int BN, int KG>
 __global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const E* __restrict__ dn, int T, int Dp, int n_pairs,
                                                           int des_shared, unsigned long long* __restrict__ row_best,
-                                                          unsigned long long* __restrict__ col_best) {
+                                                          unsigned long long* __restrict__ col_best, int hb) {
     using Tile = GemmTile<BM, BN, KG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     const int n_des = des_shared ? 1 : n_pairs;
     const E* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;   // desired frame tokens (rows i)
     const E* d2 = dn + (size_t)(n_des + b) * T * Dp;            // current frame tokens (cols j)
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const GramMap tile = gram_tile<BM, BN>(T, hb);
+    if (!tile.valid) return;                                    // (the whole workgroup: before any barrier)
+    const int i0 = tile.i0, j0 = tile.j0;
     f32x4 acc[Tile::NT][Tile::MT];
     gemm_mainloop<E, BM, BN, KG>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
     if constexpr (sizeof(E) == 2) {                                 // undo the 2^10 x 2^10 of the split (exact)
@@ -194,16 +230,18 @@ int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des
         using Tile = GemmTile<128, 128, 1>;
         static std::atomic<unsigned long long> raised{0};
         if (raise_lds_limit(reinterpret_cast<const void*>(&gram_argmax_kernel<f16, 128, 128, 1>), Tile::LDS_BYTES, raised)) return -1;
-        dim3 grid((T + 127) / 128, (T + 127) / 128, n_pairs);
-        launch((gram_argmax_kernel<f16, 128, 128, 1>), grid, dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T, 3 * Dp, n_pairs,
-               des_shared, row_best, col_best);
+        int per = 0;
+        const int hb = gram_band_rows(T, 128, 128, &per);
+        launch((gram_argmax_kernel<f16, 128, 128, 1>), dim3(8 * per, 1, n_pairs), dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T,
+               3 * Dp, n_pairs, des_shared, row_best, col_best, hb);
     } else {                                                       // 1369 tokens: 121 tiles of 128 x 128, 484 of 64 x 64
         using Tile = GemmTile<64, 64, 1>;
         static std::atomic<unsigned long long> raised{0};
         if (raise_lds_limit(reinterpret_cast<const void*>(&gram_argmax_kernel<f16, 64, 64, 1>), Tile::LDS_BYTES, raised)) return -1;
-        dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
-        launch((gram_argmax_kernel<f16, 64, 64, 1>), grid, dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T, 3 * Dp, n_pairs,
-               des_shared, row_best, col_best);
+        int per = 0;
+        const int hb = gram_band_rows(T, 64, 64, &per);
+        launch((gram_argmax_kernel<f16, 64, 64, 1>), dim3(8 * per, 1, n_pairs), dim3(256), Tile::LDS_BYTES, stream, (const f16*)dh, T,
+               3 * Dp, n_pairs, des_shared, row_best, col_best, hb);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -211,17 +249,19 @@ int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des
 int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
                        unsigned long long* col_best, hipStream_t stream) {
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
-    dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
+    int per = 0;
     if (T <= 512 && (Dp / 32) % 2 == 0) {
         // few tokens: 32x32 tiles (49 workgroups at T = 196 instead of 16) with two k-groups
         using Tile = GemmTile<32, 32, 2>;
-        dim3 g32((T + 31) / 32, (T + 31) / 32, n_pairs);
-        launch((gram_argmax_kernel<float, 32, 32, 2>), g32, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, dn, T, Dp, n_pairs, des_shared,
-                                                                                       row_best, col_best);
+        const int hb = gram_band_rows(T, 32, 32, &per);
+        launch((gram_argmax_kernel<float, 32, 32, 2>), dim3(8 * per, 1, n_pairs), dim3(Tile::THREADS), Tile::LDS_BYTES, stream, dn, T, Dp,
+               n_pairs, des_shared, row_best, col_best, hb);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
-    launch((gram_argmax_kernel<float, 64, 64, 1>), grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, row_best, col_best);
+    const int hb = gram_band_rows(T, 64, 64, &per);
+    launch((gram_argmax_kernel<float, 64, 64, 1>), dim3(8 * per, 1, n_pairs), dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared,
+           row_best, col_best, hb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -243,19 +243,29 @@ class Controller:
         z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
         v, st = compute_velocity(self.engine, cur, des, z, self.params.intrinsics(), selection=self.selection,
                                  num_pairs=self.num_pairs)
+        if not self._absorb(v, st):
+            return None, None
+        return self._features(self.engine.last_details(1), 0)
+
+    def _absorb(self, v, st) -> bool:
+        """Bookkeeping of one finished update (whoever computed it: this controller's engine, or a ``MultiController``'s batched
+        call / pipeline slot): raw twist, status, the consecutive-failure counter of vitvs_v2.py:500-505."""
         self._raw_v, self.last_status = v, st
         if st == _lib.STATUS_NO_CORRESPONDENCE:
             self.feature_failure_count += 1
             if self.feature_failure_count >= 10:
                 raise RuntimeError("Persistent feature detection failure")
-            return None, None
+            return False
         self.feature_failure_count = 0
-        det = self.engine.last_details(1)
+        return True
+
+    def _features(self, det, b: int = 0):
+        """``detect_features``' return value from pair ``b`` of an engine's ``last_details``."""
         k = self.num_pairs
-        s_uv_star = det["s_uv"][0, :k, 0:2].astype(int)
-        s_uv = det["s_uv"][0, :k, 2:4].astype(int)
-        n_matched = int(det["info"][0, 3])
-        sim = torch.from_numpy(det["feat"][0, :max(n_matched, 0), 3].astype(np.float32)).unsqueeze(0)
+        s_uv_star = det["s_uv"][b, :k, 0:2].astype(int)
+        s_uv = det["s_uv"][b, :k, 2:4].astype(int)
+        n_matched = int(det["info"][b, 3])
+        sim = torch.from_numpy(det["feat"][b, :max(n_matched, 0), 3].astype(np.float32)).unsqueeze(0)
         return (s_uv_star, s_uv), sim
 
     def ibvs(self):
@@ -263,7 +273,10 @@ class Controller:
         if self.latest_image is None:
             return
         result = self.detect_features()
-        if result is None or result[0] is None:
+        self._law_step(result is not None and result[0] is not None)
+
+    def _law_step(self, have_features: bool):
+        if not have_features:
             return
         if self.latest_image_depth is None:               # reference: "Failed to get depth - skipping"
             return
@@ -314,3 +327,166 @@ class Controller:
             if mean > best_mean:
                 best_mean, best = mean, b
         return best, scores
+
+
+# ------------------------------------------------------------------------------------------ several cameras, one GPU
+class MultiController:
+    """N cameras on ONE GPU (BASELINE.json configs[3], the 8-camera rig, when the rig has fewer GPUs than cameras).
+
+    The reference runs one ``Controller`` per camera and process (vitvs_v2.py:702-819), each with its own goal image, EMA state,
+    failure counter and history (:224, :325-343, :500-505).  Here every camera keeps exactly that state — ``self.cameras[i]`` IS a
+    ``Controller`` and is fed through its own ``image_callback_*`` — while one round of updates for all of them goes to the GPU
+    together:
+
+      backend = ``Engine`` with ``max_pairs >= N``   ONE batched call per round: the N frame pairs run through the many-row
+                                                     kernels as one launch chain (bench.py ``--pairs N``)
+      backend = ``UpdatePipeline``                   one update per camera, ``depth`` of them in flight on separate handles and
+                                                     streams (what bench.py measures ``value`` with); the cameras' inputs live in
+                                                     device buffers of their own, so every (slot, camera) replays its captured graph
+
+    Each camera's raw and smoothed ``v_c`` equal those of an independent ``Controller(Engine)`` fed the same frames and the same
+    draw (tests/test_gpu_multi.py: bit for bit).  ``selection``: "order" (a fresh random visiting order per camera and round, drawn
+    in camera order from ``generator`` / torch's global RNG, exactly the draws N ``Controller(selection="order")`` make when their
+    ``ibvs()`` are called in camera order), "dense", or — per round, through ``ibvs(selection=[ids_0, ...])`` — explicit token ids.
+    The reference's host-side sort + randperm draw ("reference") needs a host round trip per camera and stays with ``Controller``.
+    """
+
+    def __init__(self, backend, goal_images: Sequence, params: Optional[ServoParams] = None, selection: str = "order",
+                 generator: Optional[torch.Generator] = None):
+        from .pipeline import UpdatePipeline
+        self.pipe = backend if isinstance(backend, UpdatePipeline) else None
+        self.engines = list(backend.engines) if self.pipe is not None else [backend]
+        self.engine = self.engines[0]
+        if selection not in ("order", "dense"):
+            raise ValueError('MultiController draws on the device: selection is "order" or "dense" (explicit ids per round: ibvs(selection=...))')
+        self.selection, self.generator = selection, generator
+        n = len(goal_images)
+        if self.pipe is None and self.engine.max_pairs < n:
+            raise ValueError(f"engine.max_pairs ({self.engine.max_pairs}) is smaller than the number of cameras ({n})")
+        self.cameras = [Controller(self.engine, g, params, selection="order") for g in goal_images]
+        self.params = self.cameras[0].params
+        self._buffers = {}                                # pipeline mode: per-camera device inputs at stable addresses
+
+    def __len__(self):
+        return len(self.cameras)
+
+    @property
+    def v_c(self):
+        """The cameras' smoothed twists (None until a camera's first successful update), like ``Controller.v_c``."""
+        return [c.v_c for c in self.cameras]
+
+    # -- inputs: camera i's ROS callbacks
+    def image_callback_rgb(self, i: int, rgb_u8):
+        self.cameras[i].image_callback_rgb(rgb_u8)
+
+    def image_callback_depth(self, i: int, depth_u16):
+        self.cameras[i].image_callback_depth(depth_u16)
+
+    # -- one round
+    def _arrays(self, imgs):
+        out = []
+        for img in imgs:
+            if hasattr(img, "convert") and not isinstance(img, np.ndarray):   # PIL image
+                img = np.asarray(img.convert("RGB"), dtype=np.uint8)
+            out.append(img if torch.is_tensor(img) else np.asarray(img, dtype=np.uint8))
+        return out
+
+    def _frames_for(self, live):
+        """(current frames, goal frames) of the live cameras as the engines take them: one geometry for all (the usual rig) goes in
+        as it is and is resized inside the patch-row build (``Engine.set_frame_size``); anything else is resized per frame first."""
+        cur = self._arrays([self.cameras[i].latest_pil_image for i in live])
+        des = self._arrays([self.cameras[i].goal_image for i in live])
+        shapes = {tuple(a.shape[:2]) for a in cur + des}
+        if len(shapes) == 1:
+            try:
+                for e in self.engines:
+                    e.set_frame_size(*next(iter(shapes)))
+                return cur, des
+            except VitvsError:
+                pass
+        for e in self.engines:
+            e.set_frame_size()
+        ctl = self.cameras[0]
+        return [ctl._resized(a) for a in cur], [ctl._resized(a) for a in des]
+
+    def ibvs(self, selection=None, want_features: bool = False):
+        """One control-law step for every camera that has an image: each camera's ``v_c`` is updated (EMA) or left untouched on
+        failure, exactly as its own ``Controller.ibvs()`` would.  Returns the per-camera ``detect_features`` results
+        (``((s_uv_star, s_uv), sim)`` or ``(None, None)``; ``None`` for cameras without an image) when ``want_features``."""
+        live = [i for i, c in enumerate(self.cameras) if c.latest_image is not None]
+        results = [None] * len(self.cameras)
+        if not live:
+            return results if want_features else None
+        p, eng = self.params, self.engine
+        cur, des = self._frames_for(live)
+        zeros = np.zeros((p.v_max, p.u_max), np.uint16)
+        depth = [self.cameras[i].latest_image_depth if self.cameras[i].latest_image_depth is not None else zeros for i in live]
+        k = self.cameras[0].num_pairs
+        if selection is not None:
+            mode, sel = _lib.SELECT_EXPLICIT, [np.asarray(selection[i]) for i in live]
+        elif self.selection == "dense":
+            mode, sel = _lib.SELECT_DENSE, None
+        else:                                             # one fresh order per camera, drawn in camera order
+            mode = _lib.SELECT_ORDER
+            sel = [torch.randperm(eng.tokens, generator=self.generator).to(torch.int32) for _ in live]
+        if self.pipe is None:
+            stack = lambda xs: torch.stack([torch.as_tensor(x).to(eng.device) for x in xs])   # noqa: E731
+            v, st = eng.compute_velocity(stack(cur), stack(des), np.stack(depth), p.intrinsics(), mode=mode,
+                                         selection=(torch.stack(sel) if mode == _lib.SELECT_ORDER else sel), num_pairs=k)
+            v, st = v.cpu().numpy(), st.cpu().numpy()
+            det = eng.last_details(len(live)) if want_features else None
+            for j, i in enumerate(live):
+                ok = self.cameras[i]._absorb(v[j], int(st[j]))
+                if want_features:
+                    results[i] = self.cameras[i]._features(det, j) if ok else (None, None)
+                self.cameras[i]._law_step(ok)
+            return results if want_features else None
+        # pipeline: `depth` cameras in flight at a time; a slot's outputs are read before the slot is used again
+        pipe, dev = self.pipe, eng.device
+        pending = []
+
+        def collect(upto):
+            while len(pending) > upto:
+                i, t = pending.pop(0)
+                v, st = pipe.result(t)
+                ok = self.cameras[i]._absorb(v.cpu().numpy()[0], int(st[0]))
+                if want_features:
+                    results[i] = self.cameras[i]._features(pipe.engines[t % pipe.depth].last_details(1), 0) if ok else (None, None)
+                self.cameras[i]._law_step(ok)
+
+        for j, i in enumerate(live):
+            buf = self._buffers.setdefault(i, {})
+
+            def stable(name, value, dtype=None):
+                t_ = torch.as_tensor(value)
+                t_ = t_ if dtype is None else t_.to(dtype)
+                b_ = buf.get(name)
+                if b_ is None or b_.shape != t_.shape or b_.dtype != t_.dtype:
+                    b_ = torch.empty(t_.shape, dtype=t_.dtype, device=dev)
+                    buf[name] = b_
+                b_.copy_(t_, non_blocking=True)
+                return b_
+            c_ = stable("cur", cur[j])[None]
+            d_ = stable("des", des[j])[None]
+            z_ = stable("Z", depth[j])[None]
+            k_ = stable("K", torch.tensor([p.intrinsics()], dtype=torch.float64))
+            s_, n_ = None, None
+            if mode == _lib.SELECT_ORDER:
+                s_ = stable("order", sel[j])[None]
+            elif mode == _lib.SELECT_EXPLICIT:
+                ids = torch.zeros(k, dtype=torch.int32)
+                got = torch.as_tensor(sel[j], dtype=torch.int32).flatten()[:k]
+                ids[:got.numel()] = got
+                s_ = stable("ids", ids)[None]
+                n_ = stable("n_ids", torch.tensor([got.numel()], dtype=torch.int32))
+            collect(pipe.depth - 1)
+            pending.append((i, pipe.submit(c_, d_, z_, k_, mode, s_, n_, False, k)))
+        collect(0)
+        return results if want_features else None
+
+    def detect_features(self):
+        """Every camera's ``Controller.detect_features()`` result for this round (and the law step, as ``ibvs`` does it)."""
+        return self.ibvs(want_features=True)
+
+    def publish_twist(self, i: int, v_c=None):
+        return self.cameras[i].publish_twist(v_c)
