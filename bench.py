@@ -306,8 +306,12 @@ def kernel_work(cfg, n_img, n_pairs, es, binned, in_flight=1):
         "fc1": (2.0 * m * h * d, (m * d + h * d + m * h) * es),
         "fc2": (2.0 * m * d * h, (m * h + d * h) * es + s_fc2 * m * d * 4),
         "residual_ln": (12.0 * m * d, m * d * (4 + 4 * s_avg + 4 + es)),   # the last one also writes the descriptors
-        "descriptors": (3.0 * n_img * t * dp, n_img * t * (d + dp) * 4),    # binned descriptors only
-        "gram_argmax": (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4),
+        # binned descriptors: the 9 D-wide Gram is taken as a 3 x 3 stencil over the raw D-wide token Gram (correspond.hip), so the
+        # kernels' own work is: token norms, a D-wide Gram written out as T x T floats, nine adds per similarity
+        "descriptors": (2.0 * n_img * t * d, n_img * t * d * 4),            # binned only: the tokens' squared norms
+        "gram_argmax": ((2.0 * n_pairs * t * t * d, n_pairs * (2 * t * d + t * t) * 4) if binned else
+                        (2.0 * n_pairs * t * t * dp, n_pairs * 2 * t * dp * 4)),
+        "gram_stencil": (11.0 * n_pairs * t * t, n_pairs * (t * t + 4 * t) * 4),
         "servo": (0.0, n_pairs * t * 16),
     }
 

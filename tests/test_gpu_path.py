@@ -169,6 +169,39 @@ def test_descriptors_plain_and_binned():
             assert torch.equal(d[:, 0], vit_ref.log_bin(toks, cfg.grid))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("img,pairs,shared", [(96, 1, False), (80, 2, False), (224, 3, True), (512, 1, False)])
+def test_binned_correspondence_as_a_stencil_over_the_raw_gram(img, pairs, shared, precision):
+    """With binned descriptors the velocity path never builds the 9 D-wide vectors: it takes their Gram as the 3 x 3 "diagonal"
+    stencil over the raw token Gram (correspond.hip).  Against an fp64 Gram of the CONCATENATED descriptors the same engine hands
+    out (extract_descriptors(bin=True): desc_binned_kernel, itself checked against the oracle's _log_bin above): every device
+    arg-max is a maximum of that matrix up to 2e-6, sim_1 equals its row maximum — on grids of 6 x 6 and 5 x 5 (every token a
+    border or next-to-border token: the replicate clamp), 14 x 14 with a shared goal frame, and 32 x 32 (1024 tokens: the 64 x 64
+    Gram tiles; in bf16 the size from which the un-binned path takes the f16 split)."""
+    cfg = _tiny_cfg(False, img=img)
+    sd = weights.synthetic_state_dict(cfg, 5)
+    params = config.ServoParams(dino_input_size=img, use_feature_binning=True)
+    eng = _engine(cfg, params, precision=precision, max_pairs=pairs, max_rows=cfg.tokens, binned=True).load_state_dict(sd)
+    frames = [synth.frame_pair(img, 20250801 + k) for k in range(pairs)]
+    des = np.stack([f[0] for f in frames])[:1 if shared else pairs]
+    cur = np.stack([f[1] for f in frames])
+    depth = np.stack([synth.depth_pattern()] * pairs)
+    v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE, des_shared=shared)
+    det = eng.last_details(pairs)
+    assert np.all(np.isfinite(v.cpu().numpy()))
+    d = eng.extract_descriptors(np.concatenate([des, cur]), bin=True).double().cpu()[:, 0]
+    assert d.shape[-1] == 9 * cfg.dim
+    dn = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+    t = cfg.tokens
+    for b in range(pairs):
+        S = (dn[0 if shared else b] @ dn[(1 if shared else pairs) + b].T).numpy()
+        for got, M in ((det["nn_1"][b], S), (det["nn_2"][b], S.T)):
+            chosen = M[np.arange(t), got.astype(np.int64)]
+            assert float((M.max(1) - chosen).max()) <= 2e-6, "an arg-max of the stencil Gram is not a maximum of the concatenated descriptors' Gram"
+            assert float((got == M.argmax(1)).mean()) >= 0.99
+        np.testing.assert_allclose(det["sim_1"][b], S.max(1), rtol=0, atol=2e-6)
+
+
 # ----------------------------------------------------------------------------- correspondence
 CORR_CASES = ["partial", "short", "tiny", "all_mutual", "grid14", "same_image"]
 

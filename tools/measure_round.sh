@@ -2,16 +2,20 @@
 # One gpurun call that refreshes everything under profiles/ for a round (run from the repo root on the GPU box):
 #   bench lines (bf16 with CPU baseline + fp32 secondary), the other BASELINE.json configurations, rocprofv3 kernel trace +
 #   stats, three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES), micro-benchmarks.
-# usage: tools/measure_round.sh r03 <git commit>
-R="${1:-r03}"; COMMIT="${2:-unknown}"; O=gpurun_out/$R; mkdir -p $O
+# usage: tools/measure_round.sh r04 <git commit>
+R="${1:-r04}"; COMMIT="${2:-unknown}"; O=gpurun_out/$R; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
 make -C tools > /dev/null 2>&1
+# the probe build of the library (in-kernel stamps; vit-vs_amd/variants/ does not travel with gpurun, so it is built on the box)
+mkdir -p vit-vs_amd/variants/probe && make -j8 -C vit-vs_amd/csrc OUT=../variants/probe/libvitvs_hip.so BUILD=build_probe EXTRA=-DVITVS_PROBE > /dev/null 2>&1
 python bench.py > $O/bench_bf16.json 2> $O/bench_bf16.err || exit 1
 python bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err || exit 1
 python bench.py --precision fp16 --no-cpu-baseline --no-secondary > $O/bench_fp16.json 2>/dev/null || exit 1
 for b in 2 4 8; do python bench.py --pairs $b --no-cpu-baseline --no-secondary --steps 100 > $O/bench_bf16_pairs$b.json 2>/dev/null || exit 1; done
 # the other BASELINE.json configurations (parity-test cases; not the headline)
 for c in vitb8_448 vitl14_518 vits14_308 vits16_224; do python bench.py --config $c --steps 50 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > $O/bench_bf16_$c.json 2>/dev/null || exit 1; done
+# the reference's shipped default: DINOv2 ViT-S/14 308² with 3x3 log-binned descriptors (config.yaml:17)
+python bench.py --config vits14_308 --binned --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $O/bench_bf16_vits14_308_binned.json 2>/dev/null || exit 1
 python bench.py --config vitb8_448 --selection dense --steps 50 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > $O/bench_bf16_vitb8_448_dense.json 2>/dev/null || exit 1
 python bench.py --config vitl14_518 --precision fp16 --steps 50 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain > $O/bench_fp16_vitl14_518.json 2>/dev/null || exit 1
 CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-plain-chain"

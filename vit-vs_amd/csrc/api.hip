@@ -98,6 +98,7 @@ struct vitvs_handle {
     void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
     float *x = nullptr, *dn = nullptr, *sq = nullptr, *part = nullptr;  // part: split-K partial sums [8][M][D]
     unsigned short* dh = nullptr;   // fp16 hi / lo split of dn for the many-token Gram of the 16-bit modes (null: fp32 Gram)
+    float* gram_ws = nullptr;       // binned descriptors: raw token Gram [max_pairs][T][T] for the stencil form (correspond.hip; null: the 9 D-wide Gram)
     AttnWorkspace attn_ws;    // key-split states / tickets of the long-sequence attention, sized for every image count <= n_img_max
     size_t dn_elems = 0;
     unsigned long long *row_best = nullptr, *col_best = nullptr;
@@ -234,11 +235,11 @@ hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 enum KernelClass : int {
     KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
-    KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_COUNT
+    KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_GRAM_STENCIL, KC_COUNT
 };
 const char* const kClassNames[KC_COUNT] = {"patchify", "patch_embed", "layernorm", "qkv", "attention", "proj",
                                            "fc1", "fc2", "descriptors", "gram_argmax", "servo",
-                                           "residual_ln"};
+                                           "residual_ln", "gram_stencil"};
 
 // When timing is enabled, arms the launch helper (kernels.h) so that the next kernel launched inside the span
 // is dispatched with an event pair stamped with its own begin / end times.
@@ -492,11 +493,16 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     }
     h->dn_elems = (size_t)h->n_img_max * h->T * h->Dp;
     if (!rc) rc = dev_alloc(h, &h->dn, h->dn_elems);
+    // binned descriptors: the velocity path takes the 9 D-wide Gram as a 3 x 3 stencil over the raw token Gram (correspond.hip),
+    // which needs T x T floats per pair (3136 tokens: 39 MB); beyond 8 GiB in all it keeps the concatenated form
+    if (!rc && cfg->binned && (size_t)cfg->max_pairs * h->T * h->T * 4 <= (8ull << 30))
+        rc = dev_alloc(h, &h->gram_ws, (size_t)cfg->max_pairs * h->T * h->T);
     // 16-bit modes, >= 1024 tokens: the Gram runs on the f16 matrix cores from a hi / lo split of the descriptors (correspond.hip)
-    if (!rc && h->prec != PREC_F32 && h->T >= 1024 && h->Dp % 64 == 0 &&
+    if (!rc && !h->gram_ws && h->prec != PREC_F32 && h->T >= 1024 && h->Dp % 64 == 0 &&
         gram_split_elems(h->n_img_max, h->T, h->Dp) * 2 < (1ull << 32))
         rc = dev_alloc(h, &h->dh, gram_split_elems(h->n_img_max, h->T, h->Dp));
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
+
     h->best_elems = (size_t)cfg->max_pairs * h->T;
     if (!rc) rc = dev_alloc(h, &h->row_best, h->best_elems);
     if (!rc) rc = dev_alloc(h, &h->col_best, h->best_elems);
@@ -880,6 +886,19 @@ static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) 
                      : forward_chain(h, n_des, u.n_pairs, n_des, nullptr, u.I_cur, h->part, st);
     h->desc_keys = -1;
     if (rc) return rc;
+    if (h->cfg.binned && h->gram_ws) {
+        // binned descriptors as a stencil over the raw token Gram: nothing 9 D wide is built or read (correspond.hip header)
+        { Span sp(h, KC_DESCRIPTORS, st);
+          rc = launch_token_sqnorm(h->x, h->sq, n_img, h->T, h->cfg.dim, h->row_best, h->col_best, u.n_pairs * h->T, st); }
+        if (rc) return set_err(h, rc, "token norm launch failed");
+        { Span sp(h, KC_GRAM, st);
+          rc = launch_gram_raw_tokens(h->x, h->T, h->cfg.dim, u.n_pairs, u.des_shared ? 1 : 0, h->gram_ws, st); }
+        if (rc) return set_err(h, rc, "gram launch failed");
+        { Span sp(h, KC_GRAM_STENCIL, st);
+          rc = launch_gram_stencil_argmax(h->gram_ws, h->sq, h->T, h->grid, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
+        if (rc) return set_err(h, rc, "gram stencil launch failed");
+        return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.num_pairs, u.selection, u.n_selected, u.v_c, u.status, st);
+    }
     if (!desc_in_forward(h)) {
         Span sp(h, KC_DESCRIPTORS, st);
         rc = launch_descriptors(h->x, h->dn, nullptr, h->sq, n_img, h->T, h->grid, h->cfg.dim, h->cfg.binned,

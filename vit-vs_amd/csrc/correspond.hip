@@ -12,6 +12,16 @@
 //   S * 2^20 = hi1.hi2 + hi1.lo2 + lo1.hi2      (the dropped lo1.lo2 term is < 2^-22 relative)
 // as ONE contraction over 3 D: desired rows are stored [hi | hi | lo], current rows [hi | lo | hi] (split_desc_kernel).
 // ViT-B/8 448² (3136 tokens): 156 us -> see profiles/r02_notes.md.
+//
+// Binned descriptors (use_feature_binning: the reference's shipped default, config.yaml:17; _log_bin,
+// dinov2_extractor.py:265-311): the descriptor of token i is the concatenation of the 3 x 3 neighbourhood's tokens (replicate-
+// clamped at the border), so the dot product of two binned descriptors is the sum over the nine offsets d of the PLAIN dot products
+// <t_{n_d(i)}, t'_{n_d(j)}>: the 9 D-wide Gram is a 9-point "diagonal" stencil over the D-wide Gram of the raw tokens,
+//   S[i][j] = ( sum_d G[n_d(i)][n_d(j)] ) / ( |b_i| |b'_j| ),   G[i][j] = <t_i, t'_j>,   |b_i|^2 = sum_d |t_{n_d(i)}|^2 .
+// The velocity path therefore never builds the 9 D-wide descriptors: raw Gram (1 / 9 of the FLOPs and operand bytes) into a
+// T x T workspace, then gram_stencil_argmax_kernel (nine L2-resident reads per similarity).  DINOv2 ViT-S/14 308² (484 tokens,
+// 9 x 384 = 3456): 30 us + 5 us of descriptor building -> see profiles/r04_notes.md.  extract_descriptors(bin=True) still
+// returns the concatenated descriptors (elementwise.hip desc_binned_kernel); vitvs_correspond_dev takes whatever rows it is given.
 #include <algorithm>
 
 #include "gemm_core.h"
@@ -125,32 +135,111 @@ __global__ __launch_bounds__(256 * KG) void gram_argmax_kernel(const E* __restri
         }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gram_dense_kernel(const float* __restrict__ dn, int T, int Dp, int n_pairs,
-                                                         int des_shared, float* __restrict__ S) {
-    using Tile = GemmTile<BM, BN, 1>;
+// S[b][i][j] = <row i of image a(b), row j of image c(b)> over Dp elements; rows of image k start at src + k * img_stride and are
+// ld apart (normalised descriptors: img_stride = T * Dp, ld = Dp; raw tokens of the residual stream: src = x + D, img_stride =
+// (T + 1) * D, ld = D — the cls row is skipped by the base and the stride).  Tiles in the band order of gram_tile.
+template <int BM, int BN, int KG>
+__global__ __launch_bounds__(256 * KG) void gram_dense_kernel(const float* __restrict__ src, long img_stride, int ld, int T, int Dp,
+                                                              int n_pairs, int des_shared, float* __restrict__ S, int hb) {
+    using Tile = GemmTile<BM, BN, KG>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.z;
     const int n_des = des_shared ? 1 : n_pairs;
-    const float* d1 = dn + (size_t)(des_shared ? 0 : b) * T * Dp;
-    const float* d2 = dn + (size_t)(n_des + b) * T * Dp;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const float* d1 = src + (size_t)(des_shared ? 0 : b) * img_stride;
+    const float* d2 = src + (size_t)(n_des + b) * img_stride;
+    const GramMap tile = gram_tile<BM, BN>(T, hb);
+    if (!tile.valid) return;
+    const int i0 = tile.i0, j0 = tile.j0;
     f32x4 acc[Tile::NT][Tile::MT];
-    gemm_mainloop<float, BM, BN, 1>(d1, d2, Dp, Dp, T, T, i0, j0, 0, Dp, smem, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gemm_mainloop<float, BM, BN, KG>(d1, d2, ld, ld, T, T, i0, j0, 0, Dp, smem, acc);
+    const int kg = (KG == 2) ? k_group() : 0;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave & 1, wn = wave >> 1;
     float* out = S + (size_t)b * T * T;
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni)
 #pragma unroll
         for (int mi = 0; mi < Tile::MT; ++mi) {
+            if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;    // the other k-group holds this tile's sums
             const int i = i0 + wm * Tile::WM + mi * 16 + (lane & 15);
+            const int j = j0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4);
+            if (i >= T) continue;
+            float* dst = out + (size_t)i * T + j;
+            if (j + 3 < T && (T & 3) == 0) *reinterpret_cast<f32x4*>(dst) = acc[ni][mi];
+            else
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4) + r;
-                if (i < T && j < T) out[(size_t)i * T + j] = acc[ni][mi][r];
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (j + r < T) dst[r] = acc[ni][mi][r];
         }
+}
+
+// Binned similarities from the raw Gram (header): one workgroup = a 32 x 32 tile of (desired token i, current token j).
+//   G   [n_pairs][T][T]   raw dot products of the tokens (gram_dense_kernel on the residual stream)
+//   sq  [frames][T]       |t|^2 of every token (token_sqnorm_kernel), frames in the call's order: desired first
+// The nine terms are summed in the descriptor's order (dy, dx row-major: dinov2_extractor.py:302-307).
+__global__ __launch_bounds__(256) void gram_stencil_argmax_kernel(const float* __restrict__ G, const float* __restrict__ sq, int T,
+                                                                  int grid, int n_pairs, int des_shared,
+                                                                  unsigned long long* __restrict__ row_best,
+                                                                  unsigned long long* __restrict__ col_best) {
+    __shared__ float tile[32][33];
+    __shared__ float rn[64];                                       // 1 / |b| of the tile's 32 desired and 32 current tokens
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int n_des = des_shared ? 1 : n_pairs;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const float* Gb = G + (size_t)b * T * T;
+    auto clampi = [&](int v) { return min(max(v, 0), grid - 1); };
+    if (tid < 64) {
+        const int tok = (tid < 32 ? i0 : j0 - 32) + tid;
+        const float* s = sq + (size_t)(tid < 32 ? (des_shared ? 0 : b) : n_des + b) * T;
+        float tot = 0.f;
+        if (tok < T) {
+            const int y = tok / grid, x = tok - y * grid;
+#pragma unroll
+            for (int o = 0; o < 9; ++o) tot += s[clampi(y + o / 3 - 1) * grid + clampi(x + o % 3 - 1)];
+        }
+        rn[tid] = __fdiv_rn(1.0f, fmaxf(sqrtf(tot), 1e-8f));
+    }
+    const int jj = tid & 31, ii0 = tid >> 5;
+    const int j = j0 + jj, jy = j / grid, jx = j - jy * grid;
+    int nj[9];
+#pragma unroll
+    for (int o = 0; o < 9; ++o) nj[o] = clampi(jy + o / 3 - 1) * grid + clampi(jx + o % 3 - 1);
+    float acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ii0 + 8 * r, iy = i / grid, ix = i - iy * grid;
+        float a = 0.f;
+        if (i < T && j < T) {
+#pragma unroll
+            for (int o = 0; o < 9; ++o) a += Gb[(size_t)(clampi(iy + o / 3 - 1) * grid + clampi(ix + o % 3 - 1)) * T + nj[o]];
+        }
+        acc[r] = a;
+    }
+    __syncthreads();                                               // rn is in place
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[ii0 + 8 * r][jj] = acc[r] * rn[ii0 + 8 * r] * rn[32 + jj];
+    __syncthreads();
+    if (tid < 32) {                                                // best current token for desired token i0 + tid
+        const int i = i0 + tid;
+        if (i < T) {
+            unsigned long long key = 0ull;
+            for (int c = 0; c < 32 && j0 + c < T; ++c) {
+                const unsigned long long k = pack_best(tile[tid][c], (unsigned)(j0 + c));
+                key = k > key ? k : key;
+            }
+            atomicMax(row_best + (size_t)b * T + i, key);
+        }
+    } else if (tid < 64) {                                         // best desired token for current token j0 + tid - 32
+        const int c = tid - 32;
+        if (j0 + c < T) {
+            unsigned long long key = 0ull;
+            for (int r = 0; r < 32 && i0 + r < T; ++r) {
+                const unsigned long long k = pack_best(tile[r][c], (unsigned)(i0 + r));
+                key = k > key ? k : key;
+            }
+            atomicMax(col_best + (size_t)b * T + j0 + c, key);
+        }
+    }
 }
 
 __global__ void decode_best_kernel(const unsigned long long* __restrict__ rb, const unsigned long long* __restrict__ cb,
@@ -265,11 +354,39 @@ int launch_gram_argmax(const float* dn, int T, int Dp, int n_pairs, int des_shar
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream) {
+static int launch_gram_dense_strided(const float* src, long img_stride, int ld, int T, int Dp, int n_pairs, int des_shared, float* S,
+                                     hipStream_t stream) {
     if (T <= 0 || n_pairs <= 0 || (Dp % 32) != 0) return -2;
-    dim3 grid((T + 63) / 64, (T + 63) / 64, n_pairs);
-    constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
-    launch(gram_dense_kernel<64, 64>, grid, dim3(256), lds, stream, dn, T, Dp, n_pairs, des_shared, S);
+    // 32-bit byte offsets in the main loop: every row the launch touches lies within 4 GiB of its image's first row
+    if ((long long)T * ld * 4 >= (1ll << 32)) return -2;
+    int per = 0;
+    if (T <= 512 && (Dp / 32) % 2 == 0) {                       // few tokens: 32 x 32 tiles with two k-groups, like the fused arg-max form
+        using Tile = GemmTile<32, 32, 2>;
+        const int hb = gram_band_rows(T, 32, 32, &per);
+        launch((gram_dense_kernel<32, 32, 2>), dim3(8 * per, 1, n_pairs), dim3(Tile::THREADS), Tile::LDS_BYTES, stream, src, img_stride, ld,
+               T, Dp, n_pairs, des_shared, S, hb);
+    } else {
+        constexpr int lds = GemmTile<64, 64, 1>::LDS_BYTES;
+        const int hb = gram_band_rows(T, 64, 64, &per);
+        launch((gram_dense_kernel<64, 64, 1>), dim3(8 * per, 1, n_pairs), dim3(256), lds, stream, src, img_stride, ld, T, Dp, n_pairs,
+               des_shared, S, hb);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream) {
+    return launch_gram_dense_strided(dn, (long)T * Dp, Dp, T, Dp, n_pairs, des_shared, S, stream);
+}
+
+int launch_gram_raw_tokens(const float* x, int T, int D, int n_pairs, int des_shared, float* G, hipStream_t stream) {
+    return launch_gram_dense_strided(x + D, (long)(T + 1) * D, D, T, D, n_pairs, des_shared, G, stream);
+}
+
+int launch_gram_stencil_argmax(const float* G, const float* sq, int T, int grid, int n_pairs, int des_shared,
+                               unsigned long long* row_best, unsigned long long* col_best, hipStream_t stream) {
+    if (T <= 0 || n_pairs <= 0 || grid * grid != T) return -2;
+    launch(gram_stencil_argmax_kernel, dim3((T + 31) / 32, (T + 31) / 32, n_pairs), dim3(256), 0, stream, G, sq, T, grid, n_pairs,
+           des_shared, row_best, col_best);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -636,6 +636,14 @@ int launch_saliency(Precision p, const void* qkv, float* out, int n_img, int T, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int launch_token_sqnorm(const float* x, float* sq, int n_img, int T, int D, unsigned long long* zero_a, unsigned long long* zero_b,
+                        int zero_count, hipStream_t stream) {
+    const int toks = n_img * T;
+    if (toks <= 0 || zero_count > toks * 64) return -2;
+    launch(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sq, n_img, T, D, zero_a, zero_b, zero_count);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
                        int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
                        hipStream_t stream) {

@@ -149,6 +149,9 @@ int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, 
                        int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
                        hipStream_t stream);
 
+// sq[img * T + t] = |x[img][1 + t][:]|^2 (the patch tokens' squared norms); also clears zero_count words of zero_a / zero_b.
+int launch_token_sqnorm(const float* x, float* sq, int n_img, int T, int D, unsigned long long* zero_a, unsigned long long* zero_b,
+                        int zero_count, hipStream_t stream);
 // dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);
 
@@ -184,6 +187,12 @@ int launch_split_desc(const float* dn, void* dh, int T, int Dp, int n_pairs, int
 int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des_shared, unsigned long long* row_best,
                              unsigned long long* col_best, hipStream_t stream);
 int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream);
+// Binned descriptors without building them (correspond.hip header): G[b][i][j] = raw dot products of the patch tokens in the
+// residual stream x ([frames][1 + T][D] fp32, desired frames first), then the 3 x 3 "diagonal" stencil over G, normalised by the
+// binned descriptors' norms (sq = |t|^2 per token, launch_token_sqnorm), with the fused arg-max into row_best / col_best.
+int launch_gram_raw_tokens(const float* x, int T, int D, int n_pairs, int des_shared, float* G, hipStream_t stream);
+int launch_gram_stencil_argmax(const float* G, const float* sq, int T, int grid, int n_pairs, int des_shared,
+                               unsigned long long* row_best, unsigned long long* col_best, hipStream_t stream);
 
 // packed keys <-> (nn_1, sim_1, nn_2) tables for the standalone correspondence / servo entry points
 int launch_decode_best(const unsigned long long* row_best, const unsigned long long* col_best, int T, int32_t* nn1,
