@@ -276,7 +276,8 @@ static size_t frame_bytes(const vitvs_handle* h) {
 
 // One launch chain's view of the workspaces (a contiguous range of images).
 // Plain descriptors of the default forward are produced by the forward's own last launch.
-static bool desc_in_forward(const vitvs_handle* h) { return !h->cfg.binned && h->Dp == h->cfg.dim; }
+// (binned descriptors in their stencil form need only the tokens' squared norms: the same launch writes those instead)
+static bool desc_in_forward(const vitvs_handle* h) { return h->cfg.binned ? h->gram_ws != nullptr : h->Dp == h->cfg.dim; }
 
 struct ChainCtx {
     int cnt = 0, M = 0;
@@ -371,7 +372,8 @@ int forward_chain(vitvs_handle* h, int i0, int cnt, int n_des, const uint8_t* de
     ChainCtx cx = fill_ctx(h, i0, cnt, n_des, des, cur, part);
     if (h->desc_keys >= 0 && desc_in_forward(h)) {
         cx.want_desc = true;
-        cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
+        if (h->cfg.binned) cx.desc.sq = h->sq + (size_t)i0 * h->T;
+        else cx.desc.dn = h->dn + (size_t)i0 * h->T * h->Dp;
         cx.desc.zero_a = h->row_best; cx.desc.zero_b = h->col_best;
         cx.desc.T = h->T;
         cx.desc.zero_count = (i0 == 0 || h->goal_frames > 0) ? h->desc_keys : 0;   // the call's only chain clears the arg-max keys
@@ -888,9 +890,7 @@ static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) 
     if (rc) return rc;
     if (h->cfg.binned && h->gram_ws) {
         // binned descriptors as a stencil over the raw token Gram: nothing 9 D wide is built or read (correspond.hip header)
-        { Span sp(h, KC_DESCRIPTORS, st);
-          rc = launch_token_sqnorm(h->x, h->sq, n_img, h->T, h->cfg.dim, h->row_best, h->col_best, u.n_pairs * h->T, st); }
-        if (rc) return set_err(h, rc, "token norm launch failed");
+        // (the tokens' squared norms came out of the forward's last launch, which also cleared the arg-max keys)
         { Span sp(h, KC_GRAM, st);
           rc = launch_gram_raw_tokens(h->x, h->T, h->cfg.dim, u.n_pairs, u.des_shared ? 1 : 0, h->gram_ws, st); }
         if (rc) return set_err(h, rc, "gram launch failed");
@@ -979,7 +979,7 @@ int vitvs_set_goal_dev(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des, vo
     int rc = forward_chain(h, 0, n_goal, n_goal, I_des, nullptr, h->part, st);
     h->desc_keys = -1;
     if (rc) return rc;
-    h->goal_frames = n_goal;                    // (binned descriptors are rebuilt from the kept tokens by every velocity call)
+    h->goal_frames = n_goal;                    // (binned: the goal's token norms stay in h->sq, its token rows in h->x)
     return 0;
 }
 

@@ -334,8 +334,10 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < NV4; ++i)
             if (on) s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-        const float nrm = fmaxf(sqrtf(wave_sum(s2)), 1e-8f);
-        if (t >= 0 && on) {
+        const float sq = wave_sum(s2);
+        const float nrm = fmaxf(sqrtf(sq), 1e-8f);
+        if (desc.sq && t >= 0 && lane == 0) desc.sq[(size_t)img * desc.T + t] = sq;
+        if (desc.dn && t >= 0 && on) {
             float4* dst = reinterpret_cast<float4*>(desc.dn + ((size_t)img * desc.T + t) * D);
 #pragma unroll
             for (int i = 0; i < NV4; ++i)
@@ -406,7 +408,7 @@ int launch_residual_ln(Precision p, float* x, const float* part, int splits, con
     if (M <= 0 || splits < 1 || splits > SMAX) return -2;
     RlnExtra ex;
     if (!desc) return launch_rln_p<RLN_PLAIN>(p, x, part, splits, bias, ls, gamma, beta, out, M, D, eps, stream, ex);
-    if (gamma || !desc->dn || desc->T <= 0 || M % (desc->T + 1) != 0 || desc->zero_count > M * 64) return -2;
+    if (gamma || (!desc->dn && !desc->sq) || desc->T <= 0 || M % (desc->T + 1) != 0 || desc->zero_count > M * 64) return -2;
     ex.desc = *desc;
     return launch_rln_p<RLN_DESC>(p, x, part, splits, bias, ls, gamma, beta, out, M, D, eps, stream, ex);
 }
@@ -633,14 +635,6 @@ int launch_saliency(Precision p, const void* qkv, float* out, int n_img, int T, 
     if (p == PREC_F32) launch(saliency_kernel<float>, dim3(n_img), dim3(256), lds, stream, (const float*)qkv, out, T, H, hs, scale, base2);
     else if (p == PREC_F16) launch(saliency_kernel<f16>, dim3(n_img), dim3(256), lds, stream, (const f16*)qkv, out, T, H, hs, scale, base2);
     else launch(saliency_kernel<bf16>, dim3(n_img), dim3(256), lds, stream, (const bf16*)qkv, out, T, H, hs, scale, base2);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-int launch_token_sqnorm(const float* x, float* sq, int n_img, int T, int D, unsigned long long* zero_a, unsigned long long* zero_b,
-                        int zero_count, hipStream_t stream) {
-    const int toks = n_img * T;
-    if (toks <= 0 || zero_count > toks * 64) return -2;
-    launch(token_sqnorm_kernel, dim3((toks + 3) / 4), dim3(256), 0, stream, x, sq, n_img, T, D, zero_a, zero_b, zero_count);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

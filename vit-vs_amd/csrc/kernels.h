@@ -125,7 +125,8 @@ int launch_layernorm(Precision p, const float* x, const float* gamma, const floa
 // L2-normalised descriptors dn[img][t][:] = x[img][1+t][:] / max(norm, 1e-8) (rows are [img][1+T] tokens, cls
 // first) and clears zero_count 64-bit words of zero_a / zero_b (the Gram kernel's atomicMax targets).
 struct DescOut {
-    float* dn = nullptr;
+    float* dn = nullptr;          // may be null when sq is given
+    float* sq = nullptr;          // optional: sq[img * T + t] = |x[img][1 + t][:]|^2 (the stencil form of the binned Gram, correspond.hip)
     unsigned long long* zero_a = nullptr;
     unsigned long long* zero_b = nullptr;
     int T = 0;
@@ -149,9 +150,6 @@ int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, 
                        int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
                        hipStream_t stream);
 
-// sq[img * T + t] = |x[img][1 + t][:]|^2 (the patch tokens' squared norms); also clears zero_count words of zero_a / zero_b.
-int launch_token_sqnorm(const float* x, float* sq, int n_img, int T, int D, unsigned long long* zero_a, unsigned long long* zero_b,
-                        int zero_count, hipStream_t stream);
 // dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);
 
@@ -189,7 +187,7 @@ int launch_gram_argmax_split(const void* dh, int T, int Dp, int n_pairs, int des
 int launch_gram_dense(const float* dn, int T, int Dp, int n_pairs, int des_shared, float* S, hipStream_t stream);
 // Binned descriptors without building them (correspond.hip header): G[b][i][j] = raw dot products of the patch tokens in the
 // residual stream x ([frames][1 + T][D] fp32, desired frames first), then the 3 x 3 "diagonal" stencil over G, normalised by the
-// binned descriptors' norms (sq = |t|^2 per token, launch_token_sqnorm), with the fused arg-max into row_best / col_best.
+// binned descriptors' norms (sq = |t|^2 per token: DescOut::sq of the forward's last launch), with the fused arg-max into row_best / col_best.
 int launch_gram_raw_tokens(const float* x, int T, int D, int n_pairs, int des_shared, float* G, hipStream_t stream);
 int launch_gram_stencil_argmax(const float* G, const float* sq, int T, int grid, int n_pairs, int des_shared,
                                unsigned long long* row_best, unsigned long long* col_best, hipStream_t stream);
