@@ -40,8 +40,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
-STATS_PROFILE = os.path.join("profiles", "r03_kernel_stats_bf16.csv")   # rocprofv3 --kernel-trace --stats of the same command
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
+STATS_PROFILE = os.path.join("profiles", "r04_kernel_stats_bf16.csv")   # rocprofv3 --kernel-trace --stats of the same command
 
 
 # ----------------------------------------------------------------------------------------------- launcher

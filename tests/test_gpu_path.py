@@ -226,6 +226,28 @@ def test_correspond_matches_reference_argmax(small_engine, name):
     assert torch.equal(smat.max(dim=0).indices.cpu().int(), nn2.cpu())
 
 
+@pytest.mark.parametrize("g,d", [(2, 32), (7, 96), (10, 128), (17, 64), (23, 128), (30, 96), (33, 64)])
+def test_correspond_band_ordered_tiles_cover_every_token(g, d):
+    """The Gram's tiles are dealt to the XCDs band by band (correspond.hip gram_tile): token counts that are no multiple of
+    the 32 / 64-row tiles, fewer tiles than XCDs (4 tokens: one tile), ragged last bands — every row and every column must get its
+    maximum (a tile left out shows as a zero key, i.e. index 2^32 - 1), against an fp64 Gram of the normalised rows."""
+    t = g * g
+    cfg = _tiny_cfg(False, img=16 * g)
+    eng = _engine(cfg, config.ServoParams(dino_input_size=16 * g), precision="fp32", max_pairs=1, max_rows=max(t, 48))
+    gen = torch.Generator().manual_seed(100 * g + d)
+    d1, d2 = torch.randn(t, d, generator=gen), torch.randn(t, d, generator=gen)
+    nn1, nn2, sim1, smat = eng.correspond(d1, d2, want_matrix=True)
+    n1, n2 = nn1.cpu().numpy().astype(np.int64), nn2.cpu().numpy().astype(np.int64)
+    assert n1.min() >= 0 and n1.max() < t and n2.min() >= 0 and n2.max() < t
+    a = d1.double() / d1.double().norm(dim=-1, keepdim=True)
+    b = d2.double() / d2.double().norm(dim=-1, keepdim=True)
+    S = (a @ b.T).numpy()
+    assert float((S.max(1) - S[np.arange(t), n1]).max()) <= 1e-6 and float((S.max(0) - S[n2, np.arange(t)]).max()) <= 1e-6
+    np.testing.assert_allclose(sim1.cpu().numpy(), S.max(1), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(smat.cpu().numpy(), S, rtol=0, atol=1e-6)          # the dense form walks the same band order
+    eng.close()
+
+
 def test_correspond_first_index_on_exact_ties(small_engine):
     """Duplicate descriptors create exactly equal similarities; torch.max keeps the first index."""
     g = torch.Generator().manual_seed(9)
@@ -305,6 +327,85 @@ def test_servo_order_and_dense_selection_match_oracle():
     assert int(st) == 0 and det["selected"][0, :len(mutual)].tolist() == mutual.tolist()
     assert int(det["info"][0, 1]) == len(mutual)
     assert _rel_l2(v.cpu().numpy(), oracle(mutual, len(mutual))["v_c"]) <= 1e-9
+
+
+def _random_similarity(rng, t, n_boost):
+    """A random similarity matrix with `n_boost` planted mutual nearest neighbours (a random partial matching whose entries beat
+    everything in their row and column); the rest are whatever the arg-maxes of noise give."""
+    S = rng.uniform(0.2, 0.8, size=(t, t)).astype(np.float32)
+    rows = rng.permutation(t)[:n_boost]
+    cols = rng.permutation(t)[:n_boost]
+    S[rows, cols] = rng.uniform(0.85, 0.95, size=n_boost).astype(np.float32)
+    return S
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_servo_law_on_random_tables_matches_the_oracle(seed):
+    """The stage behind the arg-max tables (vitvs_v2.py:84-155, 511-553, 566-586, 613-659) on RANDOM inputs, against the oracle's
+    own functions — the reference's cyclic filter as it is written (distances, min / max normalisation, >= 1 mask), not the
+    "mutual NNs unless all are mutual" restatement the kernel uses: grids from 4 x 4 to 14 x 14, anything from four to all tokens
+    mutual, depth images with holes (0 -> the 100 m sentinel), random intrinsics, all three selection modes, explicit draws shorter
+    than 4 (the all-zero quirk) and shorter than num_pairs (the zero-padding quirk)."""
+    rng = np.random.default_rng(9000 + seed)
+    g = int(rng.integers(4, 15))
+    t = g * g
+    k = int(rng.integers(4, min(t, 48) + 1))
+    cfg = _tiny_cfg(False, img=16 * g)
+    params = config.ServoParams(num_pairs=k, dino_input_size=16 * g)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=max(k, t))
+    all_mutual = seed % 8 == 7
+    S = _random_similarity(rng, t, t if all_mutual else int(rng.integers(4, t)))
+    sim1_t, nn1_t, _, nn2_t = sr.nearest_neighbours(torch.from_numpy(S))
+    nn1, nn2, sim1 = nn1_t.numpy(), nn2_t.numpy(), sim1_t.numpy()
+    cand, _ = sr.cyclic_candidates(nn1_t, nn2_t, g)                                   # the reference's filter, literally
+    cand = np.sort(cand.numpy())
+    mutual = np.nonzero(nn2[nn1] == np.arange(t))[0]
+    assert np.array_equal(cand, mutual if len(mutual) < t else np.zeros(0, np.int64))   # the kernel's restatement, on this draw
+    depth = synth.depth_pattern().copy()
+    holes = rng.integers(0, depth.size, size=depth.size // 7)
+    depth.reshape(-1)[holes] = 0
+    K = (float(rng.uniform(300, 700)), float(rng.uniform(300, 700)), params.u_max / 2 + float(rng.uniform(-20, 20)),
+         params.v_max / 2 + float(rng.uniform(-20, 20)))
+
+    def oracle(ids, rows):
+        ids = np.asarray(ids, np.int64)
+        p1 = torch.from_numpy(np.stack([ids // g, ids % g], 1))
+        p2 = torch.from_numpy(np.stack([nn1[ids] // g, nn1[ids] % g], 1))
+        s_star, s_ = sr.calculate_uv(sr.patch_centres(p1, cfg.img_size, g), sr.patch_centres(p2, cfg.img_size, g), rows,
+                                     params.u_max, params.v_max, cfg.img_size)
+        return s_star, s_, sr.velocity(s_star, s_, depth, K[0], K[1], K[2], K[3], params.lambda_)
+
+    order = rng.permutation(t).astype(np.int32)
+    runs = [("order", _lib.SELECT_ORDER, order, None), ("dense", _lib.SELECT_DENSE, None, None)]
+    if len(cand):
+        n_exp = int(rng.integers(1, k + 1)) if seed % 3 else int(rng.integers(1, 4))    # every third seed: fewer than 4 ids
+        runs.append(("explicit", _lib.SELECT_EXPLICIT, [rng.choice(cand, size=min(n_exp, len(cand)), replace=False).astype(np.int32)], None))
+    for name, mode, sel, _ in runs:
+        v, st = eng.servo_from_nn(nn1, nn2, sim1, depth, K, mode=mode, selection=sel)
+        det = eng.last_details(1)
+        v = v.cpu().numpy()
+        if len(cand) == 0:                                                              # every token mutual: (None, None, None)
+            assert int(st) == _lib.STATUS_NO_CORRESPONDENCE and np.all(v == 0), (name, seed)
+            continue
+        if name == "order":
+            ids, rows = np.array([x for x in order if x in set(cand.tolist())][:k]), k
+        elif name == "dense":
+            ids, rows = cand, len(cand)
+        else:
+            ids, rows = sel[0], k
+        s_star, s_, ref = oracle(ids, rows)
+        want_status = _lib.STATUS_OK if len(ids) >= 4 else _lib.STATUS_TOO_FEW
+        assert int(st) == want_status, (name, seed, int(st))
+        assert int(det["info"][0, 0]) == len(mutual)
+        suv = det["s_uv"][0, :rows]
+        assert np.array_equal(suv[:, 0:2], s_star) and np.array_equal(suv[:, 2:4], s_), (name, seed)
+        if want_status == _lib.STATUS_OK:
+            assert np.array_equal(det["feat"][0, :rows, 0:1], ref["Z"]), (name, seed)
+            np.testing.assert_allclose(det["L"][0, :6, :2 * rows].T, ref["L"], rtol=0, atol=1e-13)
+            assert _rel_l2(v, ref["v_c"]) <= 1e-9 <= VC_TOL, (name, seed, _rel_l2(v, ref["v_c"]))
+        else:
+            assert np.all(v == 0.0) and not s_star.any() and not s_.any()               # calculate_uv's all-zero arrays, e = 0
+    eng.close()
 
 
 def test_servo_no_depth_status():

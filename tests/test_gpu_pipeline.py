@@ -193,3 +193,38 @@ def test_tickets_options_and_cached_goal():
         pipe.result(t0)
     pipe.synchronize()
     pipe.close()
+
+
+def test_borrowed_weights_outlive_their_lender():
+    """vitvs_share_weights shares OWNERSHIP (include/vitvs.h): the device weights are released by the last handle holding them, so
+    closing the lender first — an explicit owner.close(), which Python's garbage collector does not guard against — leaves the
+    borrowers working (it used to be a use-after-free), with eager launches and with a replayed graph that holds the addresses."""
+    dev = torch.device("cuda", 0)
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    sd = weights.synthetic_state_dict(cfg, 3)
+    _, _, des, cur, Z, K = _inputs(cfg, params, synth.RIG8_FRAME_SEEDS[:1], dev)
+    order = _orders(cfg, 1, dev)[0]
+    owner = Engine(cfg, params, precision="bf16", max_pairs=1).load_state_dict(sd)
+    want, _ = owner.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)
+    want = want.cpu().numpy().copy()
+    a = Engine(cfg, params, precision="bf16", max_pairs=1).share_weights(owner)
+    b = Engine(cfg, params, precision="bf16", max_pairs=1).share_weights(owner).set_option("graph_replay", 1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        vb, _ = b.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)      # captures b's graph while the lender lives
+        st.synchronize()
+    owner.close()                                                  # the lender goes first
+    filler = [torch.full((64, 1024, 1024), 7.0, device=dev) for _ in range(4)]               # 1 GiB of fresh allocations over whatever was freed
+    torch.cuda.synchronize()
+    va, _ = a.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)
+    with torch.cuda.stream(st):
+        vb2, _ = b.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)     # replay
+        st.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(va.cpu().numpy(), want) and np.array_equal(vb.cpu().numpy(), want) and np.array_equal(vb2.cpu().numpy(), want)
+    with pytest.raises(VitvsError, match="borrows"):
+        a.load_state_dict(sd)                                       # still a borrower: nothing can upload to those weights any more
+    del filler
+    a.close()
+    b.close()
