@@ -49,10 +49,70 @@ static double run(hipStream_t st, int reps, const std::function<int()>& op) {
     return best * 1e3 / reps;   // us
 }
 
+// "fixed" (probe build of the library: LD_LIBRARY_PATH=vit-vs_amd/variants/probe): what the fixed cost of a many-row launch is made
+// of.  Per shape on the 256 x 256 tile: the plain-chain time per launch with and without the epilogue's global stores (the output
+// burst), and in-kernel 100 MHz stamps of every workgroup (entry, first operands landed, end of the k-loop, exit) from single
+// launches with cold and with warm operands.
+static int fixed_cost_table(hipStream_t st) {
+    typedef int (*set_probe_t)(int, void*);
+    set_probe_t set_probe = (set_probe_t)dlsym(RTLD_DEFAULT, "vitvs_debug_set_big_probe");
+    if (!set_probe) { printf("fixed needs a probe build of the library\n"); return 1; }
+    struct Shape { const char* name; int M, N, K, variant; };
+    const Shape shapes[] = {{"B/8 qkv 6274x2304 K=128", 6274, 2304, 128, 256}, {"B/8 qkv 6274x2304 K=768", 6274, 2304, 768, 256},
+                            {"B/8 qkv 6274x2304 K=3072", 6274, 2304, 3072, 256}, {"8 pairs fc1 3152x3072 K=768 (256x192)", 3152, 3072, 768, 192},
+                            {"ViT-L fc1 2740x4096 K=1024 (192x256)", 2740, 4096, 1024, 1256}};
+    unsigned long long* stamps;
+    CHECK(hipMalloc((void**)&stamps, 256 * 4 * 8));
+    printf("%-40s | chain us/launch: stores, no stores | single launch, in-kernel (us after the first workgroup's entry; median over workgroups): "
+           "entry, operands landed, k-loop done, exit | the same without stores\n", "shape (256-row tiles, bf16, random)");
+    for (const Shape& s : shapes) {
+        void* A = rand_bf16((size_t)s.M * s.K, 1.0f, 1);
+        void* W[4];
+        for (int i = 0; i < 4; ++i) W[i] = rand_bf16((size_t)s.N * s.K, 0.05f, 2 + i);
+        void* out;
+        CHECK(hipMalloc(&out, (size_t)2 * s.M * s.N + 256));
+        float* bias;
+        CHECK(hipMalloc((void**)&bias, s.N * 4));
+        CHECK(hipMemset(bias, 0, s.N * 4));
+        double chain[2];
+        std::array<double, 4> med[2];
+        for (int nostore = 0; nostore < 2; ++nostore) {
+            if (set_probe(nostore, nullptr)) return 1;
+            int turn = 0;
+            chain[nostore] = run(st, 60, [&] { return vitvs_op_linear_variant(VITVS_BF16, s.variant, A, W[(turn++) % 4], bias, out, s.M, s.N, s.K, 0, 0, st); });
+            if (set_probe(nostore, stamps)) return 1;
+            std::vector<std::array<double, 4>> rows;
+            std::vector<std::vector<double>> cols(4);
+            for (int rep = 0; rep < 9; ++rep) {
+                CHECK(hipMemset(stamps, 0, 256 * 4 * 8));
+                if (vitvs_op_linear_variant(VITVS_BF16, s.variant, A, W[rep % 4], bias, out, s.M, s.N, s.K, 0, 0, st)) return 1;
+                CHECK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h(256 * 4);
+                CHECK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < 256; ++w) if (h[4 * w]) t0 = std::min(t0, h[4 * w]);
+                if (rep < 2) continue;                             // the first launches warm the code object and the caches
+                for (int w = 0; w < 256; ++w)
+                    if (h[4 * w])
+                        for (int c = 0; c < 4; ++c) cols[c].push_back((double)(h[4 * w + c] - t0) * 0.01);
+            }
+            for (int c = 0; c < 4; ++c) { std::sort(cols[c].begin(), cols[c].end()); med[nostore][c] = cols[c].empty() ? 0.0 : cols[c][cols[c].size() / 2]; }
+        }
+        printf("%-40s | %6.1f %6.1f | %5.2f %5.2f %6.2f %6.2f | %5.2f %5.2f %6.2f %6.2f\n", s.name, chain[0], chain[1], med[0][0], med[0][1], med[0][2],
+               med[0][3], med[1][0], med[1][1], med[1][2], med[1][3]);
+        fflush(stdout);
+        CHECK(hipFree(A)); CHECK(hipFree(out)); CHECK(hipFree(bias));
+        for (int i = 0; i < 4; ++i) CHECK(hipFree(W[i]));
+    }
+    set_probe(0, nullptr);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const bool fast = argc > 1 && !strcmp(argv[1], "fast");
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
+    if (argc > 1 && !strcmp(argv[1], "fixed")) return fixed_cost_table(st);
     struct Shape { const char* name; int M, N, K, gelu, slices; };
     const Shape shapes[] = {
         {"ViT-B/8 448  qkv ", 6274, 2304, 768, 0, 0},  {"ViT-B/8 448  fc1 ", 6274, 3072, 768, 1, 0},

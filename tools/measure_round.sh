@@ -64,6 +64,7 @@ tools/big_ops slices > $O/big_ops_slices.txt 2>&1
 VITVS_WEIGHT_MB=600 tools/big_ops > $O/big_ops_cold.txt 2>&1
 tools/big_ops sweep > $O/big_ops_k_sweep.txt 2>&1
 tools/big_ops attnmid > $O/attention_mid.txt 2>&1
+LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops fixed > $O/big_ops_fixed_cost.txt 2>&1
 LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops attn > $O/attention_probe.txt 2>&1
 LD_LIBRARY_PATH=vit-vs_amd/variants/probe tools/big_ops occ > $O/attention_occupancy.txt 2>&1
 fi

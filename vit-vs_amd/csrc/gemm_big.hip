@@ -46,7 +46,8 @@ struct BigTile {
     static constexpr int STAGE = 2 * A_SLOT + 2 * B_SLOT;
     static constexpr int RING = 2 * STAGE;
     static constexpr int WAVE_REGION = RING / 8;                      // epilogue image of one wave
-    static constexpr int LDS_BYTES = RING;
+    static constexpr int BIAS_OFFSET = RING;                          // the tile's BN bias values (fp32) behind the ring
+    static constexpr int LDS_BYTES = RING + BN * 4;
     static_assert(WGM * WGN == 8 && MT % 2 == 0 && NT % 2 == 0, "8 waves, even tile counts");
     static_assert(A_ROWS % 8 == 0 && B_ROWS % 8 == 0 && BH % 8 == 0 && AH % 8 == 0, "half slots are made of 8-row copies");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -70,7 +71,7 @@ struct BigStore {      // out[m][n] = act(sum + bias[n]) in the operand type
     T* out;
     const float* bias;
     int ldo, gelu;
-    __device__ __forceinline__ float4 column_terms(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    static constexpr bool HAS_BIAS = true;
     __device__ __forceinline__ f32x4 apply(f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
@@ -90,9 +91,17 @@ struct BigPartial {    // part[z][m][n] = raw fp32 sums of k slice z
     typedef float Out;
     float* out;
     int ldo;
-    __device__ __forceinline__ float4 column_terms(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static constexpr bool HAS_BIAS = false;
     __device__ __forceinline__ f32x4 apply(f32x4 v, float4) const { return v; }
 };
+
+#ifdef VITVS_PROBE
+// probe builds only (tools/big_ops fixed): what a launch's fixed cost is made of.  bit 0: the epilogue runs but its global stores are
+// not issued (the output burst); per workgroup, the cycle counter at entry, after the prologue's first landing and at the end of
+// the k-loop goes to g_big_probe (3 words per workgroup) when it is set.
+__device__ int g_big_probe_flags;
+__device__ unsigned long long* g_big_probe;
+#endif
 
 template <typename T, class Tile, class Epi>
 __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict__ A, const T* __restrict__ W,
@@ -138,6 +147,11 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
     bool first_tile = true;
+#ifdef VITVS_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long probe_t1 = 0, probe_t2 = 0;
+    const bool probe_nostore = (g_big_probe_flags & 1) != 0;
+#endif
   for (int it = local; it < blk_tiles; it += stride) {
     int tz, ty, tx;
     if (xmap == 0) {
@@ -214,15 +228,35 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- the tile's bias values go to LDS behind the ring.  Requested BEFORE the prologue's copies: vector-memory operations
+    // retire in order, so the prologue's counted wait below (all but the FULL youngest copies) covers this load without
+    // waiting for anything it would not wait for anyway — where the epilogue used to start with a dependent global load of
+    // its column terms (1 - 1.3 us per tile between the last k-tile and the first output store: profiles/r04_notes.md section 4).
+    // Inline asm: for an ordinary load hipcc would drain every LDS-DMA copy in flight at the load's first use.
+    u32x4 bias_raw = {0u, 0u, 0u, 0u};
+    const bool bias_lane = Epi::HAS_BIAS && wave == 0 && lane < Tile::BN / 4;
+    if constexpr (Epi::HAS_BIAS) {
+        if (bias_lane) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_raw) : "v"(bias + n0 + 4 * lane) : "memory");
+    }
     // ---- prologue: k-tile 0 whole, k-tile 1's first halves, in the steady-state order
     issue_a(0, 0); issue_b(0, 0); issue_b(1, 0); issue_a(1, 0);
     issue_a(0, 1); issue_b(0, 1);
     wait_vmcnt<FULL>();                                  // A0(0), B0(0) have landed (this wave's copies)
+    if constexpr (Epi::HAS_BIAS) {
+        if (bias_lane) {
+            asm volatile("" : "+v"(bias_raw));           // (the wait above retired the load: it is older than every copy)
+            *reinterpret_cast<u32x4*>(smem + Tile::BIAS_OFFSET + 16 * lane) = bias_raw;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in LDS before the barriers that follow
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();                        // ... and every other wave's
     if (wave >= 4) __builtin_amdgcn_s_barrier();         // stagger: the second group runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
+#ifdef VITVS_PROBE
+    if (probe_t1 == 0) probe_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // fragment registers: the current A half, both B halves
     u32x4 xa[MT / 2][2], wb[2][NT / 2][2];
@@ -300,6 +334,9 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 #undef VITVS_BIG_PHASE
     if (wave < 4) __builtin_amdgcn_s_barrier();          // the first group's matching extra barrier
     __builtin_amdgcn_sched_barrier(0);
+#ifdef VITVS_PROBE
+    probe_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // every wave has passed its last LDS read and every copy has landed (vmcnt 0 above): the ring is free
 
     // ---- epilogue through a wave-private LDS image, then whole-row stores
@@ -318,10 +355,13 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     constexpr int PASS_MT = (MT * 16 * ROW_BYTES <= Tile::WAVE_REGION) ? MT : MT / 2;
     static_assert(PASS_MT * 16 * ROW_BYTES <= Tile::WAVE_REGION, "epilogue image does not fit");
     static_assert((CHUNKS & (CHUNKS - 1)) == 0 && CHUNKS <= 64 && NT % NTG == 0, "row chunks");
-    // per-column terms (bias): requested here rather than before the k-loop — 16 registers the loop cannot spare
+    // per-column terms (bias) from the LDS copy the prologue left behind the ring (registers the k-loop cannot spare)
     float4 col[NT];
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) col[ni] = epi.column_terms(n0 + wc * (NT * 16) + ni * 16 + 4 * ge);
+    for (int ni = 0; ni < NT; ++ni) {
+        if constexpr (Epi::HAS_BIAS) col[ni] = *reinterpret_cast<const float4*>(smem + Tile::BIAS_OFFSET + 4 * (wc * (NT * 16) + ni * 16 + 4 * ge));
+        else col[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     unsigned char* img = smem + wave * Tile::WAVE_REGION;
     O* obase = out + (size_t)tz * M * N;
     const int wm0 = m0 + wr * (MT * 16), wn0 = n0 + wc * (NT * 16);
@@ -368,6 +408,9 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
                 // write-through (sc1): the rows leave for memory as they are stored instead of waiting, dirty in this XCD's
                 // L2, for the write-back at the kernel boundary (measured -3 ... -7 % on these launches: all of a tile's
                 // output is produced at its very end, so there is nothing for a write-back cache to merge)
+#ifdef VITVS_PROBE
+                if (probe_nostore) { asm volatile("" :: "v"(rowv[i])); continue; }
+#endif
                 if (m < M)
                     store_out16<true>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0 + cg * NTG * 16) + chunk * 16, rowv[i]);
             }
@@ -376,7 +419,20 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
       }
     }
   }   // next tile of this workgroup
+#ifdef VITVS_PROBE
+    if (g_big_probe && tid == 0) {
+        unsigned long long* dst = g_big_probe + 4 * (size_t)blockIdx.x;
+        dst[0] = probe_t0; dst[1] = probe_t1; dst[2] = probe_t2; dst[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
+
+#ifdef VITVS_PROBE
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_big_probe(int flags, void* stamps) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe_flags), &flags, sizeof(flags)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe), &stamps, sizeof(stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------- launch side
 typedef BigTile<2, 4, 8, 4> Tile256x256;
