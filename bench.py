@@ -843,6 +843,59 @@ def run_rank(args):
                                note="one update in flight, goal tokens cached (vitvs_set_goal_dev): only the current frame is forwarded; the "
                                     "reference recomputes I_des every update, and so does `value`")
 
+        # The boundary's host-buffer form (vitvs_compute_velocity: frames, depth, intrinsics and the visiting order in HOST memory,
+        # v_c back in host memory, one synchronous call per update): the PCIe-inclusive rate of one control loop.  Never `value`.
+        host_buffers = None
+        if world == 1 and rank == 0 and not args.no_secondary and not dense:
+            import ctypes as C
+            hp = lambda a: a.ctypes.data_as(C.c_void_p)                       # noqa: E731
+            k_host = np.ascontiguousarray(np.array([params.intrinsics()] * B, np.float64))
+            z_host = np.ascontiguousarray(np.stack([depth_np] * B))
+            orders_host = orders[:8].cpu().numpy().copy()
+            v_out, st_out = np.zeros((B, 6), np.float64), np.zeros(B, np.int32)
+            eng.set_option("in_flight", 1)
+
+            def host_step(i):
+                rc = eng.lib.vitvs_compute_velocity(eng.handle, B, hp(cur_np), hp(des_np), 0, hp(z_host), hp(k_host), _lib.SELECT_ORDER,
+                                                    hp(orders_host[i % 8]), None, 0, hp(v_out), hp(st_out))
+                if rc != 0:
+                    raise RuntimeError(f"vitvs_compute_velocity failed ({rc})")
+            h_steps = max(10, args.steps // 2)
+            for i in range(3):
+                host_step(i)
+            t_h = time.perf_counter()
+            for i in range(h_steps):
+                host_step(3 + i)
+            el_h = time.perf_counter() - t_h
+            host_buffers = dict(metric="servo_updates_per_sec", value=round(B * h_steps / el_h, 2), unit="updates/s", steps=h_steps,
+                                ms_per_step=round(el_h / h_steps * 1e3, 4), dtype=args.precision,
+                                bytes_over_pcie_per_update=int(B * (2 * cfg.img_size ** 2 * 3 + depth_np.nbytes + 32 + cfg.tokens * 4 + 52)),
+                                note="host-pointer entry point, pageable numpy buffers in, v_c out, one synchronous call per update "
+                                     "on one handle (the PCIe-inclusive form of `sequential`); `value` is device-resident by contract")
+
+        # fp16: the same kernels on v_mfma_f32_16x16x32_f16 — the throughput dtype for trained checkpoints (DESIGN.md section 3:
+        # 96-99.5 % arg-max agreement on trained-like weights where bf16 keeps 77-91 %); same protocol as `value`, fewer steps
+        same_kernels_fp16 = None
+        if world == 1 and rank == 0 and not args.no_secondary and not dense and args.precision == "bf16" and pipe is not None:
+            pipe16 = UpdatePipeline(cfg, params, sd, precision="fp16", depth=in_flight, max_pairs=B, device=dev)
+
+            def step16(i):
+                pipe16.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+
+            def fence16():
+                pipe16.synchronize()
+                torch.cuda.synchronize(dev)
+            for i in range(2 * in_flight):
+                step16(i)
+            fence16()
+            f_steps, f_warm = max(20, args.steps // 2), max(5, args.warmup // 2)
+            el16 = timed_updates(None, step16, fence16, f_warm, f_steps, dev)
+            same_kernels_fp16 = dict(metric="servo_updates_per_sec", value=round(B * f_steps / el16, 2), unit="updates/s", dtype="fp16",
+                                     steps=f_steps, warmup=f_warm, ms_per_step=round(el16 / f_steps * 1e3, 4),
+                                     note=f"{in_flight} updates in flight, fp16 operands: the recommended throughput dtype for trained "
+                                          "checkpoints (tests/test_gpu_path.py::test_trained_like_statistics_end_to_end)")
+            pipe16.close()
+
     updates = world * B * args.steps
     value = updates / elapsed
     es = 4 if args.precision == "fp32" else 2
@@ -987,6 +1040,8 @@ def run_rank(args):
         sequential=sequential,
         secondary=secondary,
         goal_cached=goal_cached,
+        host_buffers=host_buffers,
+        same_kernels_fp16=same_kernels_fp16,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),
                   tflops=round(cfg.flops_per_pair(binned) * value / world / 1e12, 3),
                   frac_of_mfma_peak=round(cfg.flops_per_pair(binned) * value / world / PEAK_MFMA[args.precision], 5),
