@@ -27,10 +27,11 @@ from .engine import Engine, VitvsError
 
 class UpdatePipeline:
     """``depth`` updates in flight.  ``submit`` enqueues one update and returns a ticket; ``result(ticket)`` waits for that
-    update alone.  A slot's output buffers are reused every ``depth`` submissions: read (or ``result``) a ticket before
+    update alone.  ``precision`` defaults to fp16: bf16 runs the same kernels at the same speed, but on weights with trained-like
+    statistics its arg-max correspondences follow the fp32 reference's far less closely.  A slot's output buffers are reused every ``depth`` submissions: read (or ``result``) a ticket before
     submitting ``depth`` more."""
 
-    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "bf16", depth: int = 3,
+    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 3,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
                  plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True,
                  stage_inputs: bool = False):
