@@ -16,9 +16,10 @@ from vitvs_amd.pipeline import UpdatePipeline
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
     key = sys.argv[2] if len(sys.argv) > 2 else "vitb16_224"      # e.g. vitb8_448: the key-split long-sequence attention
+    binned = len(sys.argv) > 3 and sys.argv[3] == "binned"        # the stencil form of the binned Gram (raw Gram workspace per slot)
     dev = torch.device("cuda", 0)
     cfg = config.baseline_config(key)
-    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=binned)
     sd = weights.synthetic_state_dict(cfg, 0)
     seeds = synth.RIG8_FRAME_SEEDS if key == "vitb16_224" else [synth.ACCEPTED_FRAME_SEEDS[key] + i for i in range(8)]
     pairs = [synth.frame_pair(cfg.img_size, s) for s in seeds]
@@ -45,7 +46,7 @@ def main():
         bad += first.setdefault(j % P, v) != v
     dt = time.perf_counter() - t0
     free1 = torch.cuda.mem_get_info(dev)[0]
-    print(f"{key}: {n} updates through 3 slots in {dt:.2f} s ({n / dt:.0f} updates/s with a host read per update), "
+    print(f"{key}{' binned' if binned else ''}: {n} updates through 3 slots in {dt:.2f} s ({n / dt:.0f} updates/s with a host read per update), "
           f"{len(first)} distinct (pair, order) cases, results differing from their first pass: {bad}, "
           f"device memory in use changed by {(free0 - free1) / 2**20:.1f} MiB")
     sys.exit(1 if bad else 0)
