@@ -172,3 +172,24 @@ def test_failures_and_missing_inputs_stay_per_camera(rig):
     # identical frames take the same-image shortcut of find_correspondences_batch (mean similarity > 0.99): features with zero error
     assert mc.cameras[1].last_status == 0 and np.all(np.asarray(mc.cameras[1]._raw_v) == 0.0)
     eng.close()
+
+
+@pytest.mark.parametrize("backend", ["batched", "pipeline"])
+def test_camera_resolution_frames_through_the_multi_camera_adapter(rig, backend):
+    """Cameras deliver 640 x 480 frames (vitvs_v2.py:455-458); the adapter hands them to the engines as they are and the reference's
+    PIL resize (:474-475) happens inside the patch-row build (Engine.set_frame_size on every engine of the backend).  Three cameras,
+    four rounds: bit-identical to three independent Controller(Engine), which take the same fused path."""
+    from PIL import Image
+    cfg, params, sd, (goals, frames, depth) = rig
+    big = lambda a: np.array(Image.fromarray(a).resize((640, 480), Image.BILINEAR), dtype=np.uint8)   # noqa: E731  (any 640 x 480 content)
+    goals3 = [big(g) for g in goals[:3]]
+    frames3 = [[big(f) for f in frames[c][:4]] for c in range(3)]
+    prec = "fp32"
+    want = _run_independent(cfg, params, sd, prec, goals3, frames3, depth[:3], seed=21, in_flight=3 if backend == "pipeline" else 1)
+    be = (Engine(cfg, params, precision=prec, max_pairs=3).load_state_dict(sd) if backend == "batched"
+          else UpdatePipeline(cfg, params, sd, precision=prec, depth=3))
+    got = _run_multi(be, goals3, frames3, depth[:3], seed=21)
+    _same(got, want)
+    engines = be.engines if backend == "pipeline" else [be]
+    assert all(e.frame_size == (480, 640) for e in engines)
+    be.close()
