@@ -73,7 +73,10 @@ typedef struct vitvs_config {
     float std[3];
     float ln_eps;         /* 1e-6 */
     int32_t precision;    /* vitvs_precision of the ViT GEMMs/attention; the correspondence and the law are fp32/fp64 */
-    int32_t binned;       /* 1: 3x3 log-bin descriptors (use_feature_binning, dinov2_extractor.py:265-311) */
+    int32_t binned;       /* 1: 3x3 log-bin descriptors (use_feature_binning, dinov2_extractor.py:265-311).  The velocity calls take
+                           * the similarities of the 9D-wide descriptors as a 3x3 stencil over the D-wide Gram of the raw tokens
+                           * (same values to fp32 rounding; one T x T fp32 workspace per pair); the extract_* calls return the
+                           * concatenated descriptors */
     /* control law (reference: config.yaml:1-17; vitvs_v2.py:278-295) */
     int32_t num_pairs;    /* default feature-pair count of a call that passes num_pairs <= 0 */
     int32_t u_max, v_max; /* camera resolution; also the depth image size */
@@ -213,7 +216,8 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
  * cameras / control loops sharing the GPU, or a frame stream run as a pipeline) overlap when they are enqueued through
  * DIFFERENT handles on DIFFERENT streams: one call in flight per handle, any number of handles (vit-vs_amd/pipeline.py is
  * that arrangement; measured: profiles/r03_notes.md section 5).  Per-handle options for it:
- *   "graph_replay" 0 / 1   velocity calls replay a hipGraph captured per argument tuple (host cost ~50 us per update
+ *   "graph_replay" 0 / 1   velocity calls replay a hipGraph captured per argument tuple — up to 32 tuples per handle, least
+ *                          recently used evicted — (host cost ~50 us per update
  *                          instead of ~370 us of launch calls, so ONE host thread keeps several streams busy; on a single
  *                          stream plain launches are ~2 % faster, hence the default 0, or the VITVS_GRAPH environment variable
  *                          at creation).  The reference has no counterpart (one torch call chain per update, vitvs_v2.py:464-523).
