@@ -234,7 +234,8 @@ VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value)
  * the Infinity Cache for all queues (a copy per handle: 4 x 172 MB cycle through its 256 MB).  `src` must own its weights and
  * have all of them (vitvs_weights_ready); uploads go to `src` only (vitvs_set_tensor on `h` is error -5).  Ownership is shared:
  * the device memory is released when the LAST handle holding it is destroyed, so `src` and `h` may be destroyed in any order
- * (a borrower whose lender is gone keeps working; nothing can upload to those weights any more). */
+ * (a borrower whose lender is gone keeps working; nothing can upload to those weights any more).  A borrower may borrow
+ * again, from another owner: the call drains the device and drops the updates captured over the previous weights. */
 VITVS_API int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src);
 
 /* --- measurement hooks (bench.py roofline leg) --------------------------------------------------

@@ -228,3 +228,30 @@ def test_borrowed_weights_outlive_their_lender():
     del filler
     a.close()
     b.close()
+
+
+def test_a_borrower_that_changes_lender_replays_over_the_new_weights():
+    """A handle that borrowed from one owner and then borrows from another drops the updates it captured over the first owner's
+    weights: its next call (graph replay on, same argument tuple) runs on the second owner's."""
+    dev = torch.device("cuda", 0)
+    cfg = config.baseline_config("vits16_224")
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    _, _, des, cur, Z, K = _inputs(cfg, params, synth.RIG8_FRAME_SEEDS[:1], dev)
+    order = _orders(cfg, 1, dev)[0]
+    owners = [Engine(cfg, params, precision="bf16", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, s)) for s in (3, 4)]
+    want = [o.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)[0].cpu().numpy().copy() for o in owners]
+    assert not np.array_equal(want[0], want[1])
+    b = Engine(cfg, params, precision="bf16", max_pairs=1).share_weights(owners[0]).set_option("graph_replay", 1)
+    st = torch.cuda.Stream()
+    got = []
+    with torch.cuda.stream(st):
+        for o in (owners[0], owners[0], owners[1], owners[1]):
+            b.share_weights(o)
+            v, _ = b.compute_velocity_dev(cur[0], des[0], Z, K, _lib.SELECT_ORDER, order)
+            st.synchronize()
+            got.append(v.cpu().numpy().copy())
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[0])
+    assert np.array_equal(got[2], want[1]) and np.array_equal(got[3], want[1])
+    b.close()
+    for o in owners:
+        o.close()

@@ -233,6 +233,16 @@ int check_cfg(const vitvs_config* c, std::string& why) {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Captured updates hold addresses (weights, resize tables) and a tile plan: whoever changes one of those drops them, after
+// the device has drained (a replay may still be running).
+void drop_graphs(vitvs_handle* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
 enum KernelClass : int {
     KC_PATCHIFY = 0, KC_PATCH_EMBED, KC_LAYERNORM, KC_QKV, KC_ATTENTION, KC_PROJ, KC_FC1, KC_FC2, KC_DESCRIPTORS,
     KC_GRAM, KC_SERVO, KC_RESIDUAL_LN, KC_GRAM_STENCIL, KC_COUNT
@@ -540,10 +550,8 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
 void vitvs_destroy(vitvs_handle* h) {
     if (!h) return;
     DeviceScope dev(h);
-    for (auto& g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    (void)hipDeviceSynchronize();               // nothing of this handle's is in flight when its graphs and memory go
+    drop_graphs(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
@@ -559,6 +567,11 @@ int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src) {
     if (!h->have.empty() && !h->borrowed) return set_err(h, -5, "this handle already holds weights of its own");
     if (src->borrowed) return set_err(h, -5, "share from the handle that owns the weights");
     if (vitvs_weights_ready(src) != 0) return set_err(h, -4, "the source handle's weights are not fully loaded");
+    if (!h->graphs.empty()) {                   // borrowed before, from another owner: captured updates read THOSE weights
+        DeviceScope dev(h);
+        VITVS_HIP_CHECK(hipDeviceSynchronize());
+        drop_graphs(h);
+    }
     h->blk = src->blk;
     h->pe_w = src->pe_w; h->pe_b = src->pe_b; h->cls = src->cls; h->pos = src->pos;
     h->have = src->have;
@@ -754,11 +767,7 @@ int vitvs_set_frame_size(vitvs_handle* h, int32_t in_h, int32_t in_w) {
     // commit.  Captured updates hold the previous tables' addresses: they go (a cached goal's tokens do not depend on the
     // geometry and stay)
     VITVS_HIP_CHECK(hipDeviceSynchronize());
-    for (auto& g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
-    h->graphs.clear();
+    drop_graphs(h);
     (void)resize_tables(h, h->fr, 0, 0);            // frees the previous tables
     h->fr = fresh;
     if (new_cur) {
@@ -1082,14 +1091,6 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
             for (size_t c = 0; c < 7; ++c) memset(L + (b * 7 + c) * 2 * R + 2 * n, 0, (2 * R - 2 * n) * 8);
     }
     return 0;
-}
-
-static void drop_graphs(vitvs_handle* h) {
-    for (auto& g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
-    h->graphs.clear();
 }
 
 int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value) {
