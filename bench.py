@@ -14,7 +14,7 @@ weights, graph replay per slot, the in-flight tile plan); W warm-up steps, then 
 device synchronisations, as for one stream.  The line's `sequential` object is the same W + K steps with ONE update in flight
 (one handle, one stream, plain launches) — what `value` was in rounds 1-2 — measured first, on every rank.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--pairs B] [--config KEY] [--in-flight D]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|f16x2|fp32] [--pairs B] [--config KEY] [--in-flight D]
 
 `--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts the N ranks itself — one process
 per GPU, before this process touches a GPU — and relays rank 0's line; it fails if fewer than N devices are visible.
@@ -38,7 +38,10 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before HIP initialises (s
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense, MI355X_MICROARCH.md
+# dense, MI355X_MICROARCH.md.  f16x2 (split-f16: three f16 MFMAs per k-step for fp32-class results) is priced against the SAME f16
+# peak on its algorithmic FLOPs — a third of the peak is the most the scheme can reach, said beside every fraction it reports
+PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "f16x2": 2.5e15, "fp32": 157.3e12}
+ELEM_BYTES = {"bf16": 2, "fp16": 2, "f16x2": 4, "fp32": 4}       # bytes per logical operand element (f16x2: an fp16 hi / lo pair)
 PEAK_HBM = 8.0e12
 TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
 STATS_PROFILE = os.path.join("profiles", "r04_kernel_stats_bf16.csv")   # rocprofv3 --kernel-trace --stats of the same command
@@ -50,7 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "f16x2", "fp32"],
+                    help="operand type of the forward; f16x2 = split-f16 (fp16 hi / lo pairs, fp32-class results: the parity mode at servo rate)")
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per step per GPU")
     ap.add_argument("--config", default="vitb16_224")
     ap.add_argument("--selection", default="order", choices=["order", "dense"],
@@ -61,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--binned", action="store_true",
                     help="3x3 log-binned descriptors (use_feature_binning: true, the reference's shipped default with "
                          "--config vits14_308: config.yaml:17, vitvs_v2.py:482-493); the Gram's K becomes 9 D")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: skip the per-update v_c all-gather (every rank keeps its own twists: SURVEY 8(e) allows it); "
+                         "with and without it the driver can separate the collective's cost from the compute")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 parity-mode leg")
     ap.add_argument("--no-plain-chain", action="store_true",
@@ -324,10 +331,11 @@ def plain_chain_us(prec, m, n, k, slices, dev, reps=300):
     import torch
     from vitvs_amd import _lib
     lib = _lib.load()
-    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32}[prec]
-    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[prec]
-    a = torch.zeros((m, k), dtype=dt, device=dev)
-    ws = [torch.zeros((n, k), dtype=dt, device=dev) for _ in range(12)]   # 12 weight sets, like the 12 blocks
+    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32, "f16x2": _lib.F16X2}[prec]
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "f16x2": torch.float16}[prec]
+    kw = 2 * k if prec == "f16x2" else k                                  # f16x2 rows: an fp16 hi / lo pair per element
+    a = torch.zeros((m, kw), dtype=dt, device=dev)
+    ws = [torch.zeros((n, kw), dtype=dt, device=dev) for _ in range(12)]   # 12 weight sets, like the 12 blocks
     part = torch.zeros((slices, m, n), dtype=torch.float32, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -359,10 +367,11 @@ def overlapped_chain_us(prec, m, d, hidden, s_proj, s_fc2, dev, queues=3, blocks
     import torch
     from vitvs_amd import _lib
     lib = _lib.load()
-    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32}[prec]
-    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[prec]
+    code = {"bf16": _lib.BF16, "fp16": _lib.F16, "fp32": _lib.F32, "f16x2": _lib.F16X2}[prec]
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "f16x2": torch.float16}[prec]
     g = torch.Generator(device="cpu").manual_seed(3)
-    rnd = lambda *shape: (torch.randn(shape, generator=g) * 0.05).to(dt).to(dev)   # noqa: E731  (random data: zeros run at a higher clock)
+    wide = 2 if prec == "f16x2" else 1                                   # f16x2 rows: an fp16 hi / lo pair per element
+    rnd = lambda r, c: (torch.randn((r, c * wide), generator=g) * 0.05).to(dt).to(dev)   # noqa: E731  (random data: zeros run at a higher clock)
     w_proj = [rnd(d, d) for _ in range(blocks)]
     w_fc2 = [rnd(d, hidden) for _ in range(blocks)]
     per_queue = []
@@ -670,7 +679,8 @@ def run_rank(args):
     # N > 1: one v_c all-gather per update (torch.distributed on RCCL), enqueued behind the update on the update's own stream.
     # VITVS_ASYNC_GATHER=1 (one update in flight only) issues it asynchronously on RCCL's stream with alternating buffers
     # (vit-vs_amd/dist.py: VelocityGather) — measured SLOWER on one GPU in a world of one rank (0.577 vs 0.464 ms per update).
-    async_gather = (multi and os.environ.get("VITVS_DIST_BACKEND", "nccl") == "nccl"
+    do_gather = multi and not args.no_gather
+    async_gather = (do_gather and os.environ.get("VITVS_DIST_BACKEND", "nccl") == "nccl"
                     and os.environ.get("VITVS_ASYNC_GATHER") == "1" and pipe is None)
     gather = vdist.VelocityGather(world * B, dev) if async_gather else None
     v_slots = [v, torch.zeros_like(v)]
@@ -688,7 +698,7 @@ def run_rank(args):
                 engine.compute_velocity_dev(I_cur, goal, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, vi, status)
             if async_gather:
                 gather.post(vi, i)
-            elif multi:
+            elif do_gather:
                 vdist.gather_velocities(vi, world * B, out=v_all)
         return step
     step = make_step(eng)
@@ -708,7 +718,7 @@ def run_rank(args):
             t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False)
         else:
             t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
-        if multi:                                   # the update's v_c all-gather, behind it on its own stream
+        if do_gather:                               # the update's v_c all-gather, behind it on its own stream
             v_k, _, st_k = pipe.slot(t)
             with torch.cuda.stream(st_k):
                 vdist.gather_velocities(v_k, world * B, out=v_all_slots[t % in_flight])
@@ -717,38 +727,50 @@ def run_rank(args):
         pipe.synchronize()
         fence()
 
+    def rank_spread(el):
+        """ms per step of this rank's timed region, reduced over the ranks: the job's figure is the max (the contract), the
+        min beside it shows whether one rank lags the others."""
+        t = torch.tensor([el / args.steps * 1e3], dtype=torch.float64, device=dev)
+        lo, hi, tot = t.clone(), t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        return dict(min=round(float(lo.item()), 4), max=float(hi.item()), mean=round(float(tot.item()) / world, 4))
+
     sequential = None
     with torch.cuda.stream(stream):
         if pipe is not None:
             # first the same updates one at a time on one stream — rounds 1-2's `value`, same W and K, with its per-update
             # all-gather at N > 1 — then the pipelined leg that `value` reports (every rank runs both, in this order)
             el_seq = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
+            seq_rank_ms = None
             if multi:
-                ts = torch.tensor([el_seq], dtype=torch.float64, device=dev)
-                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-                el_seq = float(ts.item())
+                seq_rank_ms = rank_spread(el_seq)
+                el_seq = seq_rank_ms["max"] * args.steps * 1e-3
             sequential = dict(metric="servo_updates_per_sec", value=round(world * B * args.steps / el_seq, 2), unit="updates/s",
                               steps=args.steps, warmup=args.warmup, ms_per_step=round(el_seq / args.steps * 1e3, 4),
                               note="one update in flight per GPU: one handle, one stream, plain launches, the one-stream tile "
                                    "plan (what `value` was in rounds 1-2); measured before the pipelined leg")
+            if seq_rank_ms:
+                sequential["per_rank_ms_per_step"] = dict(seq_rank_ms, max=round(seq_rank_ms["max"], 4))
             for i in range(2 * in_flight):          # set-up, not warm-up: every slot captures its graph (first call) and
                 pipe_step(i)                        # uploads the instantiated graph (first replay) before anything is timed
             pipe_fence()
             elapsed = timed_updates(None, pipe_step, pipe_fence, args.warmup, args.steps, dev)
             last = (pipe.submitted - 1) % in_flight
             v.copy_(pipe.v[last]); status.copy_(pipe.status[last])
-            if multi:
+            if do_gather:
                 v_all.copy_(v_all_slots[last])
         else:
             elapsed = timed_updates(eng, step, fence, args.warmup, args.steps, dev)
+        rank_ms = None
         if multi:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            elapsed = float(te.item())
+            rank_ms = rank_spread(elapsed)              # every rank's own clock: a straggler shows as max >> min
+            elapsed = rank_ms["max"] * args.steps * 1e-3
         status_host = status.cpu().numpy().copy()
         v_host = v_slots[(args.warmup + args.steps - 1) & 1].cpu().numpy().copy() if async_gather else v.cpu().numpy().copy()
         gathered_ok, ranks_seen = None, None
-        if multi and not async_gather:
+        if do_gather and not async_gather:
             ok = torch.tensor([int(torch.equal(v_all[rank * B:(rank + 1) * B], v))], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # EVERY rank finds its own rows in the gathered table
             gathered_ok = bool(ok.item())
@@ -797,13 +819,13 @@ def run_rank(args):
         eng_prof.timing_enable(False)
         plain = None
         if rank == 0 and world == 1 and not args.no_plain_chain:   # single-process extra; ranks stay in lock step at N > 1
-            m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
+            m_rows, bk_ = 2 * B * cfg.seq, 128 // ELEM_BYTES[args.precision]
             plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_, in_flight), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
         overlapped = None
         if rank == 0 and world == 1 and not args.no_plain_chain and in_flight > 1:
-            m_rows, bk_ = 2 * B * cfg.seq, 128 // (4 if args.precision == "fp32" else 2)
+            m_rows, bk_ = 2 * B * cfg.seq, 128 // ELEM_BYTES[args.precision]
             try:                                     # an auxiliary figure: it must never cost the line
                 overlapped = overlapped_chain_us(args.precision, m_rows, cfg.dim, cfg.hidden, split_k(m_rows, cfg.dim, cfg.dim, bk_, in_flight),
                                                  split_k(m_rows, cfg.dim, cfg.hidden, bk_, in_flight), dev, queues=in_flight)
@@ -817,18 +839,49 @@ def run_rank(args):
         if world == 1 and rank == 0 and not args.no_cpu_baseline and not dense:
             # (the handle and tile plan `value` was measured with: a pipeline slot when several updates are in flight)
             parity = parity_block(eng_prof, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K, orders[0, 0], _lib)
-        if world == 1 and rank == 0 and not args.no_secondary and args.precision != "fp32" and not dense:
-            # the parity mode (fp32 operands on the exact-fp32 MFMA) in the same process, same inputs and orders
-            eng32 = Engine(cfg, params, precision="fp32", max_pairs=B).load_state_dict(sd)
-            s_steps, s_warm = max(10, args.steps // 4), max(3, args.warmup // 4)
-            el32 = timed_updates(eng32, make_step(eng32), fence, s_warm, s_steps, dev)
-            secondary = dict(dtype="fp32", metric="servo_updates_per_sec", value=round(B * s_steps / el32, 2), unit="updates/s",
-                             steps=s_steps, warmup=s_warm, ms_per_step=round(el32 / s_steps * 1e3, 4),
-                             note="one update in flight.  Parity mode: v_c <= 1e-4 and bit-exact arg-max are asserted in this mode "
-                                  "(tests/test_gpu_path.py); its MFMA ceiling is 157 TFLOP/s -> ~2.2 k updates/s")
+        if world == 1 and rank == 0 and not args.no_secondary and args.precision in ("bf16", "fp16") and not dense:
+            # The parity mode at servo rate: split-f16 (VITVS_F16X2: every operand an fp16 hi / lo pair, three f16 MFMAs per
+            # k-step) — the precision every fp32-mode parity test also runs under, unchanged bars (tests/test_gpu_path.py EXACT) —
+            # same process, same inputs and orders, one update in flight and `in_flight` in flight like `value`; the fp32
+            # matrix pipe's own rate (the mode of the earlier rounds' `secondary`) beside it.
+            eng_x2 = Engine(cfg, params, precision="f16x2", max_pairs=B).load_state_dict(sd)
+            s_steps, s_warm = max(10, args.steps // 2), max(3, args.warmup // 2)
+            el_x2 = timed_updates(eng_x2, make_step(eng_x2), fence, s_warm, s_steps, dev)
+            secondary = dict(dtype="f16x2", metric="servo_updates_per_sec", value_one_in_flight=round(B * s_steps / el_x2, 2),
+                             unit="updates/s", steps=s_steps, warmup=s_warm, ms_per_step_one_in_flight=round(el_x2 / s_steps * 1e3, 4),
+                             note="split-f16 parity mode: fp32-class results (bit-exact arg-max tables on the strict fixtures, tokens "
+                                  "<= 2e-5, v_c <= 1e-9: the fp32 tests of tests/test_gpu_path.py run under it unchanged) on the f16 "
+                                  "matrix cores; operand bytes as fp32, three MFMAs per k-step")
             if not args.no_cpu_baseline:
-                secondary["parity"] = parity_block(eng32, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K,
+                secondary["parity"] = parity_block(eng_x2, cfg, sd, params, des_np[0], cur_np[0], depth_np, I_cur, I_des, Z, K,
                                                    orders[0, 0], _lib)
+            eng_x2.close()
+            if pipe is not None:
+                pipe_x2 = UpdatePipeline(cfg, params, sd, precision="f16x2", depth=in_flight, max_pairs=B, device=dev)
+
+                def x2_step(i):
+                    pipe_x2.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+
+                def x2_fence():
+                    pipe_x2.synchronize()
+                    torch.cuda.synchronize(dev)
+                for i in range(2 * in_flight):
+                    x2_step(i)
+                x2_fence()
+                el_p = timed_updates(None, x2_step, x2_fence, s_warm, s_steps, dev)
+                secondary.update(value=round(B * s_steps / el_p, 2), ms_per_step=round(el_p / s_steps * 1e3, 4),
+                                 updates_in_flight=in_flight)
+                pipe_x2.close()
+            else:
+                secondary.update(value=secondary["value_one_in_flight"], ms_per_step=secondary["ms_per_step_one_in_flight"],
+                                 updates_in_flight=1)
+            eng32 = Engine(cfg, params, precision="fp32", max_pairs=B).load_state_dict(sd)
+            f_steps32, f_warm32 = max(10, args.steps // 8), 3
+            el32 = timed_updates(eng32, make_step(eng32), fence, f_warm32, f_steps32, dev)
+            secondary["fp32_matrix_pipe"] = dict(value_one_in_flight=round(B * f_steps32 / el32, 2), steps=f_steps32,
+                                                 ms_per_step=round(el32 / f_steps32 * 1e3, 4),
+                                                 note="the same updates on v_mfma_f32_16x16x4_f32 (157 TFLOP/s dense peak -> a ceiling "
+                                                      "of ~2.2 k updates/s): what the split-f16 mode replaces as the parity mode")
             eng32.close()
 
         # NOT the headline: the same updates with the goal frame's tokens computed once (vitvs_set_goal_dev) — what a servo
@@ -870,8 +923,41 @@ def run_rank(args):
             host_buffers = dict(metric="servo_updates_per_sec", value=round(B * h_steps / el_h, 2), unit="updates/s", steps=h_steps,
                                 ms_per_step=round(el_h / h_steps * 1e3, 4), dtype=args.precision,
                                 bytes_over_pcie_per_update=int(B * (2 * cfg.img_size ** 2 * 3 + depth_np.nbytes + 32 + cfg.tokens * 4 + 52)),
-                                note="host-pointer entry point, pageable numpy buffers in, v_c out, one synchronous call per update "
-                                     "on one handle (the PCIe-inclusive form of `sequential`); `value` is device-resident by contract")
+                                note="host-pointer entry point (vitvs_compute_velocity), pageable numpy buffers in, v_c out, one synchronous "
+                                     "call per update on one handle: memcpy into the handle's pinned block, one copy launch for the frames, "
+                                     "the depth image copied behind the forward's launches and read in place by the law (the PCIe-inclusive "
+                                     "form of `sequential`); `value` is device-resident by contract")
+
+        # The drop-in's own rate: the reference's Controller.ibvs() (vitvs_v2.py:588-632) through vit-vs_amd/servo.py — camera
+        # frames (u_max x v_max uint8, the fused Pillow resize) and the uint16 depth image as HOST numpy arrays, handed over by the
+        # callbacks before every step like the reference's ROS callbacks do; one handle, one update at a time, EMA and feature
+        # arrays included.  selection "order": the device-side draw (one C call per update); "reference": the reference's own
+        # sort + randperm draw on the host between the correspondence and the law (two device round trips).
+        controller_loop = None
+        if world == 1 and rank == 0 and not args.no_secondary and not dense and B == 1:
+            from PIL import Image
+            from vitvs_amd import servo as vservo
+            cam = lambda a: np.asarray(Image.fromarray(a).resize((params.u_max, params.v_max)), dtype=np.uint8)   # noqa: E731
+            goal_cam, cur_cam = cam(des_np[0]), cam(cur_np[0])
+            eng_c = Engine(cfg, params, precision=args.precision, max_pairs=1).load_state_dict(sd)
+            controller_loop = dict(frames=f"{params.u_max}x{params.v_max} uint8 host arrays + uint16 depth, fused Pillow-exact resize",
+                                   dtype=args.precision, note="Controller.ibvs() per update incl. the callbacks' hand-over, the draw, "
+                                   "EMA and the feature arrays the reference's detect_features returns; one update in flight")
+            for sel_name in ("order", "reference"):
+                ctl = vservo.Controller(eng_c, goal_image=goal_cam, selection=sel_name)
+                ctl.generator = torch.Generator().manual_seed(121)
+                n_loop, lat_c = 230, []
+                for i in range(n_loop):
+                    ctl.image_callback_rgb(cur_cam)
+                    ctl.image_callback_depth(depth_np)
+                    t_c = time.perf_counter()
+                    ctl.ibvs()
+                    lat_c.append(time.perf_counter() - t_c)
+                lat_c = np.array(lat_c[30:]) * 1e3
+                controller_loop[sel_name] = dict(updates=len(lat_c), updates_per_s=round(1e3 / float(lat_c.mean()), 1),
+                                                 median_ms=round(float(np.median(lat_c)), 4), p90_ms=round(float(np.percentile(lat_c, 90)), 4),
+                                                 v_c_is_set=ctl.v_c is not None, status=ctl.last_status)
+            eng_c.close()
 
         # fp16: the same kernels on v_mfma_f32_16x16x32_f16 — the throughput dtype for trained checkpoints (DESIGN.md section 3:
         # 96-99.5 % arg-max agreement on trained-like weights where bf16 keeps 77-91 %); same protocol as `value`, fewer steps
@@ -898,7 +984,7 @@ def run_rank(args):
 
     updates = world * B * args.steps
     value = updates / elapsed
-    es = 4 if args.precision == "fp32" else 2
+    es = ELEM_BYTES[args.precision]
     work = kernel_work(cfg, 2 * B, B, es, binned, in_flight)
     kernels = {}
     for name, (ms, cnt) in prof.items():
@@ -911,7 +997,7 @@ def run_rank(args):
                              tflops=round(fl / avg / 1e12, 3), gbps=round(by / avg / 1e9, 1))
     # roofline object: the kernel SYMBOL with the largest share of the step (proj and fc2 are the same
     # split-K kernel, as rocprofv3 --stats reports them), priced with its algorithmic work per launch
-    prec_tag = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision]
+    prec_tag = {"bf16": "bf16", "fp16": "f16", "fp32": "f32", "f16x2": "hx2"}[args.precision]
     groups = {"linear_partial(proj+fc2)": ["proj", "fc2"]}
     for k in kernels:
         if k not in ("proj", "fc2"):
@@ -929,7 +1015,7 @@ def run_rank(args):
     def linear_symbol(m, n, kk, s_, partial):   # the kernel symbol of the tile the LIBRARY reports for this layer (no mirror)
         import ctypes
         tile = (ctypes.c_int32 * 3)()
-        prec_id = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16}[prec_tag]
+        prec_id = {"f32": _lib.F32, "bf16": _lib.BF16, "f16": _lib.F16, "hx2": _lib.F16X2}[prec_tag]
         prev_hint = eng.lib.vitvs_op_plan_in_flight(in_flight)       # the plan `value` ran under; restored at once
         rc_ = eng.lib.vitvs_op_linear_tile(prec_id, m, n, kk, s_ if partial else 0, tile)
         eng.lib.vitvs_op_plan_in_flight(prev_hint)
@@ -938,17 +1024,24 @@ def run_rank(args):
         if tile[2] == 0:
             return f"linear_big_kernel<{prec_tag},{tile[0]}x{tile[1]}>:" + ("BigPartial" if partial else "BigStore")
         return f"linear_kernel<{prec_tag},{tile[0]},{tile[1]},{tile[2]}>:" + ("EpiPartial" if partial else "EpiStore")
+    def attention_symbol(tag, cfg_, b_):     # mirror of launch_attention's dispatch (attention.hip)
+        short = cfg_.seq <= 256 and -(-cfg_.seq // 16) * cfg_.heads * 2 * b_ <= 640
+        if tag == "f32":
+            return "attention_f32_kernel"
+        if tag == "hx2":
+            return "attention_x2_short_kernel" if short else "attention_x2_kernel"
+        if short:
+            return f"attention_16_short_kernel<{tag}>"
+        if cfg_.seq >= 512 or (cfg_.seq >= 128 and -(-cfg_.seq // 64) * cfg_.heads * 2 * b_ > 256):
+            return f"attention_16_long_kernel<{tag}>"
+        return f"attention_16_kernel<{tag}>"
     m_all = 2 * B * cfg.seq
     bk_es = 128 // es
     symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es, in_flight), True),
               "residual_ln": f"residual_ln_kernel<{prec_tag}>",
               "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, False),
               "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, False),
-              "attention": "attention_f32_kernel" if prec_tag == "f32" else
-                           (f"attention_16_short_kernel<{prec_tag}>" if cfg.seq <= 256 and -(-cfg.seq // 16) * cfg.heads * 2 * B <= 640 else
-                            (f"attention_16_long_kernel<{prec_tag}>"
-                             if cfg.seq >= 512 or (cfg.seq >= 128 and -(-cfg.seq // 64) * cfg.heads * 2 * B > 256)
-                             else f"attention_16_kernel<{prec_tag}>"))}.get(dom, dom)
+              "attention": attention_symbol(prec_tag, cfg, B)}.get(dom, dom)
     # HBM traffic (PMC) comes from separate rocprofv3 --pmc passes of this same command, never from this run: the line
     # says which committed file and which commit of the kernels it was measured on, and mixes it into no live ratio.
     traffic, traffic_source = None, None
@@ -986,6 +1079,11 @@ def run_rank(args):
                     unit="TFLOP/s", frac=round(fl / avg_s / peak, 5), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_flops_per_launch=fl, algorithmic_bytes_per_launch=by,
                     avg_launch_us=round(avg_s * 1e6, 3))
+        if args.precision == "f16x2" and dom != "gram_argmax":
+            roof["executed_flops_per_launch"] = 3 * fl
+            roof["frac_of_split_ceiling"] = round(3 * fl / avg_s / peak, 5)
+            roof["note"] = ("split-f16: hi.hi + hi.lo + lo.hi = three f16 MFMAs per algorithmic MAC, so peak / 3 is the scheme's "
+                            "ceiling; `achieved` / `frac` price the ALGORITHMIC FLOPs against the full f16 peak")
         if from_profile:
             from_profile["achieved"] = round(fl / (from_profile["avg_ns"] * 1e-9) / 1e12, 3)
             from_profile["frac"] = round(fl / (from_profile["avg_ns"] * 1e-9) / peak, 5)
@@ -1026,8 +1124,8 @@ def run_rank(args):
                              f"{'3x3 log-binned descriptors (9 D wide); ' if binned else ''}"
                              f"{B} pair(s) per update, {in_flight} independent update(s) in flight",
                     key=args.config, binned=binned, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=in_flight, tokens=cfg.tokens, dim=cfg.dim,
-                    parallelism=(f"dp{world} (frame pairs sharded, v_c all-gather per step"
-                                 f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
+                    parallelism=(f"dp{world} (frame pairs sharded, " + ("no collective" if not do_gather else "v_c all-gather per step")
+                                 + f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
                     weights="synthetic seed 0", frame_seeds=seeds, selection="DENSE" if dense else "ORDER"),
         protocol=(f"{in_flight} independent batch-{B} updates in flight per GPU (one handle + one high-priority stream each, shared "
                   f"weights, hipGraph replay, the in_flight tile plan); the timed region is K updates between two barrier + "
@@ -1041,6 +1139,7 @@ def run_rank(args):
         secondary=secondary,
         goal_cached=goal_cached,
         host_buffers=host_buffers,
+        controller_loop=controller_loop,
         same_kernels_fp16=same_kernels_fp16,
         path=dict(gflop_per_update=round(cfg.flops_per_pair(binned) / 1e9, 3),
                   tflops=round(cfg.flops_per_pair(binned) * value / world / 1e12, 3),
@@ -1053,6 +1152,10 @@ def run_rank(args):
         status=[int(s) for s in status_host],
         v_c=[float(x) for x in v_host[0]],
     )
+    if rank_ms is not None:
+        out["per_rank_ms_per_step"] = dict(rank_ms, max=round(rank_ms["max"], 4))
+        out["v_c_gather"] = ("none (--no-gather: every rank keeps its own twists)" if not do_gather else
+                             "one all-gather of 6 doubles per pair behind every update")
     if gathered_ok is not None:
         out["gathered_rows_match_local"] = gathered_ok
     if ranks_seen is not None:

@@ -42,7 +42,12 @@ typedef struct vitvs_handle vitvs_handle;
 /* operand type of the GEMMs and of attention (accumulation is always fp32, the residual stream, LayerNorm statistics,
  * descriptors and the correspondence fp32, the control law fp64): F32 = parity mode, BF16 = throughput mode, F16 = the
  * other 16-bit mode (BASELINE.json configs[4] names fp16; 11-bit significand, same speed as bf16) */
-enum vitvs_precision { VITVS_F32 = 0, VITVS_BF16 = 1, VITVS_F16 = 2 };
+/* VITVS_F16X2 ("split-f16"): every GEMM / attention operand is kept as an fp16 hi / lo pair (22 significant bits) and every
+ * contraction runs as hi.hi + hi.lo + lo.hi on the f16 matrix cores with fp32 accumulation: the reference's fp32 arithmetic
+ * (dinov2_extractor.py:245-263: no autocast anywhere) to fp32 rounding, at 16-bit matrix rate instead of the fp32 matrix
+ * pipe's 1/16 of it.  The parity mode at servo rate; same results class as VITVS_F32 (bit-exact arg-max tables on the
+ * fixtures, tokens to 2e-5). */
+enum vitvs_precision { VITVS_F32 = 0, VITVS_BF16 = 1, VITVS_F16 = 2, VITVS_F16X2 = 3 };
 
 /* Servo status (reference error convention):
  *   NO_CORRESPONDENCE  find_correspondences_batch returned (None, None, None)   vitvs_v2.py:155, 500-505

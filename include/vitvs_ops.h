@@ -53,6 +53,11 @@ VITVS_API int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out
  *   x[M][D] (fp32) += ls[D] * (sum_z part[z] + bias)  (slices summed in index order); then, if gamma != NULL,
  *   out[M][D] = LayerNorm(x) * gamma + beta in `precision` (out may be NULL when gamma is NULL). */
 VITVS_API int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K);
+/* VITVS_F16X2 operands of the hooks: A / qkv rows and W rows hold 2 C fp16 per C logical columns, [hi of 32 columns | lo of the
+ * same 32] per 64 fp16 (csrc/common.h), outputs likewise; W may carry a power of two 2^e (e = 0 .. 31, what the handle's weight
+ * upload does so that the lo halves are normal fp16 numbers): this sets e for the calling thread's later vitvs_op_linear* calls
+ * (the sums leave multiplied by 2^-e).  e outside 0 .. 31 only reads.  Returns the previous value. */
+VITVS_API int vitvs_op_weight_exponent(int32_t e);
 /* The plan hint a handle carries as its "in_flight" option (vitvs.h), for the pointer-only hooks of this header: the calling
  * thread's later vitvs_op_* calls plan as if n updates were in flight (n >= 1; n < 1 only reads).  Returns the previous value. */
 VITVS_API int vitvs_op_plan_in_flight(int32_t n);

@@ -77,3 +77,48 @@ def test_asynchronous_velocity_gather_two_ranks():
         assert got.shape == (steps, 2, 6)
         for i in range(steps):
             assert torch.all(got[i, 0] == 100.0 * i + 0) and torch.all(got[i, 1] == 100.0 * i + 1)
+
+
+def _pipeline_worker(rank, world, port, n_pairs, depth, steps, ret):
+    """What one rank of `bench.py --gpus N` does with `depth` updates in flight (bench.py pipe_step): update i runs on slot
+    i % depth, its local rows are gathered into THAT slot's table, and a slot's table is only rewritten `depth` updates later —
+    so after every update the tables of the `depth` most recent updates must all be complete and intact."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = vdist.shard_range(n_pairs, rank, world)
+    rows = torch.arange(b, e, dtype=torch.float64)[:, None] * 10.0 + torch.arange(6, dtype=torch.float64)[None, :]
+    v_slots = [torch.zeros((e - b, 6), dtype=torch.float64) for _ in range(depth)]
+    tables = [torch.zeros((n_pairs, 6), dtype=torch.float64) for _ in range(depth)]
+    all_rows = torch.arange(n_pairs, dtype=torch.float64)[:, None] * 10.0 + torch.arange(6, dtype=torch.float64)[None, :]
+    ok = True
+    for i in range(steps):
+        k = i % depth
+        v_slots[k].copy_(rows + 1000.0 * i)                   # update i's twists of this rank's pairs
+        vdist.gather_velocities(v_slots[k], n_pairs, out=tables[k])
+        for back in range(min(depth, i + 1)):                 # the depth most recent updates, each in its own slot
+            j = i - back
+            ok = ok and bool(torch.equal(tables[j % depth], all_rows + 1000.0 * j))
+    ret[rank] = (ok, tables[(steps - 1) % depth].clone())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [8, 11])
+def test_pipelined_gathers_on_eight_ranks_with_ragged_shards(n_pairs):
+    """World size 8 (the node the driver scales to), even (8 pairs: BASELINE.json configs[3], one camera per GPU) and ragged
+    (11 pairs: shards of 2, 2, 2, 1, 1, 1, 1, 1) shards, three slots round-robin as bench.py issues them."""
+    world, depth, steps = 8, 3, 7
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(world, port, n_pairs, depth, steps, ret), nprocs=world, join=True)
+    want = torch.arange(n_pairs, dtype=torch.float64)[:, None] * 10.0 + torch.arange(6, dtype=torch.float64)[None, :] + 1000.0 * (steps - 1)
+    for rank in range(world):
+        ok, last = ret[rank]
+        assert ok, f"rank {rank}: a slot's table was incomplete or overwritten early"
+        assert torch.equal(last, want)
+    sizes = [vdist.shard_range(n_pairs, r, world) for r in range(world)]
+    assert sum(e - b for b, e in sizes) == n_pairs and max(e - b for b, e in sizes) - min(e - b for b, e in sizes) <= 1

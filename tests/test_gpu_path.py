@@ -20,6 +20,9 @@ from conftest import golden_case, load_golden
 pytestmark = pytest.mark.gpu
 
 VC_TOL = 1e-4  # north_star: relative L2 on v_c
+# The two precisions held to the fp32 bars (bit-exact arg-max tables on the strict fixtures, tokens <= 2e-5, v_c <= 1e-9): the fp32
+# matrix pipe, and split-f16 (VITVS_F16X2: hi / lo fp16 pairs, three f16 MFMAs per k-step) — the same tests, unchanged bars.
+EXACT = ["fp32", "f16x2"]
 
 
 def _engine(cfg, params=None, **kw):
@@ -117,49 +120,53 @@ class _PlanRunner:
 
 
 # ----------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("layerscale", [False, True])
-def test_forward_tokens_tiny_fp32(layerscale):
+def test_forward_tokens_tiny_fp32(layerscale, exact):
     cfg = _tiny_cfg(layerscale)
     sd = weights.synthetic_state_dict(cfg, 11)
     frames = np.random.default_rng(0).integers(0, 256, size=(3, cfg.img_size, cfg.img_size, 3), dtype=np.uint8)
-    eng = _engine(cfg, precision="fp32", max_pairs=2).load_state_dict(sd)
+    eng = _engine(cfg, precision=exact, max_pairs=2).load_state_dict(sd)
     got = eng.forward_tokens(frames).cpu()
     ref = _oracle_tokens(cfg, sd, frames)
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
-def test_forward_tokens_resampled_pos_embed_and_stride():
+@pytest.mark.parametrize("exact", EXACT)
+def test_forward_tokens_resampled_pos_embed_and_stride(exact):
     """Strided (overlapping) patch embedding + bicubic pos-embed resampling (dinov2_extractor.py:85-144)."""
     base = config.vit_config("dino_vits16", 64, stride=8)
     cfg = dataclasses.replace(base, dim=128, depth=1, heads=2, layer=0, native_grid=4)
     sd = weights.synthetic_state_dict(cfg, 5)
     frames = np.random.default_rng(1).integers(0, 256, size=(2, 64, 64, 3), dtype=np.uint8)
-    eng = _engine(cfg, precision="fp32", max_pairs=1).load_state_dict(sd)
+    eng = _engine(cfg, precision=exact, max_pairs=1).load_state_dict(sd)
     got = eng.forward_tokens(frames).cpu()
     ref = _oracle_tokens(cfg, sd, frames)
     assert got.shape == (2, 1 + 49, 128)
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("key", ["vits16_224", "vitb16_224", "vits14_308"])
-def test_forward_tokens_fp32_full_size(key):
+def test_forward_tokens_fp32_full_size(key, exact):
     blob = load_golden(f"e2e_{key}.npz")
     cfg = config.baseline_config(key)
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
-    eng = _engine(cfg, precision="fp32", max_pairs=1).load_state_dict(sd)
+    eng = _engine(cfg, precision=exact, max_pairs=1).load_state_dict(sd)
     got = eng.forward_tokens(np.stack([des, cur])).cpu()
     np.testing.assert_allclose(got[:, ::37, ::97].numpy(), blob["token_probe"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(got.norm(dim=-1).numpy(), blob["token_norms"], rtol=1e-5)
 
 
-def test_descriptors_plain_and_binned():
+@pytest.mark.parametrize("exact", EXACT)
+def test_descriptors_plain_and_binned(exact):
     cfg = _tiny_cfg(False, img=96)
     sd = weights.synthetic_state_dict(cfg, 3)
     frames = np.random.default_rng(2).integers(0, 256, size=(2, 96, 96, 3), dtype=np.uint8)
     ref = _oracle_tokens(cfg, sd, frames)[:, 1:]
     for binned in (False, True):
-        eng = _engine(cfg, precision="fp32", max_pairs=1, binned=binned).load_state_dict(sd)
+        eng = _engine(cfg, precision=exact, max_pairs=1, binned=binned).load_state_dict(sd)
         d = eng.extract_descriptors(frames).cpu()
         want = vit_ref.log_bin(ref, cfg.grid) if binned else ref
         assert d.shape == (2, 1, cfg.tokens, cfg.dim * (9 if binned else 1))
@@ -169,7 +176,7 @@ def test_descriptors_plain_and_binned():
             assert torch.equal(d[:, 0], vit_ref.log_bin(toks, cfg.grid))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
 @pytest.mark.parametrize("img,pairs,shared", [(96, 1, False), (80, 2, False), (224, 3, True), (512, 1, False)])
 def test_binned_correspondence_as_a_stencil_over_the_raw_gram(img, pairs, shared, precision):
     """With binned descriptors the velocity path never builds the 9 D-wide vectors: it takes their Gram as the 3 x 3 "diagonal"
@@ -458,11 +465,12 @@ def _e2e(key, tag, precision, plan="alone"):
     return out
 
 
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("plan", PLANS)
 @pytest.mark.parametrize("key,tag", [("vits16_224", "plain"), ("vits16_224", "binned"), ("vitb16_224", "plain"),
                                      ("vitb16_224", "binned"), ("vits14_308", "binned")])
-def test_compute_velocity_fp32_matches_reference(key, tag, plan):
-    case, det, v, st = _e2e(key, tag, "fp32", plan)
+def test_compute_velocity_fp32_matches_reference(key, tag, plan, exact):
+    case, det, v, st = _e2e(key, tag, exact, plan)
     assert bool(case["strict"])
     assert st == 0
     assert np.array_equal(det["nn_1"][0], case["nn_1"])   # bit-exact argmax correspondences
@@ -473,8 +481,9 @@ def test_compute_velocity_fp32_matches_reference(key, tag, plan):
     assert _rel_l2(v, case["v_c"]) <= 1e-9 <= VC_TOL
 
 
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("key,tag", [("vitb16_224", "plain"), ("vits14_308", "binned")])
-def test_cached_goal_gives_the_reference_update(key, tag):
+def test_cached_goal_gives_the_reference_update(key, tag, exact):
     """vitvs_set_goal_dev: the goal frame forwarded once, later calls pass I_des = None and forward only the current frame.
     Against the reference-generated fixture exactly like the recomputing call (bit-exact tables, v_c <= 1e-9), twice in a
     row (the cache survives a cached call), and the cache is dropped by any call that forwards frames of its own."""
@@ -485,7 +494,7 @@ def test_cached_goal_gives_the_reference_update(key, tag):
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=(tag == "binned"))
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=1).load_state_dict(sd)
     sel = _ids(case["points1"], cfg.grid)
     depth = synth.depth_pattern()
     with pytest.raises(VitvsError):                       # nothing cached yet
@@ -503,7 +512,7 @@ def test_cached_goal_gives_the_reference_update(key, tag):
         eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[sel])
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "f16x2"])
 def test_cached_shared_goal_batch_matches_the_recomputing_call(precision):
     """One cached goal against three current frames (the rotation search's layout): the same arg-max tables and twists as the
     call that forwards the goal again, up to the GEMMs' summation order (4 images there, 3 here: other tiles)."""
@@ -525,7 +534,7 @@ def test_cached_shared_goal_batch_matches_the_recomputing_call(precision):
         a1 = float((det["nn_1"][b] == det_ref["nn_1"][b]).mean())
         a2 = float((det["nn_2"][b] == det_ref["nn_2"][b]).mean())
         assert a1 >= 0.99 and a2 >= 0.99, (b, a1, a2)
-        np.testing.assert_allclose(det["sim_1"][b], det_ref["sim_1"][b], rtol=0, atol=2e-5 if precision == "fp32" else 2e-2)
+        np.testing.assert_allclose(det["sim_1"][b], det_ref["sim_1"][b], rtol=0, atol=2e-5 if precision in EXACT else 2e-2)
         # DENSE selection: v_c is the oracle's law on the call's OWN tables, checked for both calls (never skipped); equal
         # tables then give equal twists
         for dd, vv in ((det, v), (det_ref, v_ref)):
@@ -544,11 +553,12 @@ def _tie_tolerant_agreement(got, ref_idx, sim_ref_rows, tol):
     return 1.0 - len(bad) / len(ref_idx)
 
 
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("key", ["vitl14_518", "vitb8_448"])
-def test_compute_velocity_fp32_many_tokens(key):
+def test_compute_velocity_fp32_many_tokens(key, exact):
     """BASELINE configs #3/#5: thousands of tokens, top-1/top-2 margins ~1e-6, so index parity is
     judged tie-tolerantly against the oracle's similarity matrix; v_c given the reference selection."""
-    case, det, v, st = _e2e(key, "plain", "fp32")
+    case, det, v, st = _e2e(key, "plain", exact)
     cfg = config.baseline_config(key)
     blob = load_golden(f"e2e_{key}.npz")
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
@@ -744,7 +754,8 @@ def test_forward_tokens_fp16_large_config(key):
     assert torch.isfinite(got).all() and rel <= 1e-3        # fp16 tokens to 7e-4 (measured 6.9e-4)
 
 
-def test_forward_tokens_strided_full_size():
+@pytest.mark.parametrize("exact", EXACT)
+def test_forward_tokens_strided_full_size(exact):
     """SURVEY §8(f)3 at full size: dino_vits8 with stride 4 at 224² -> 55 x 55 = 3025 overlapping patches (the long-sequence
     case the stride hack exists for, dinov2_extractor.py:122-144), pos_embed resampled 28 -> 55 (:94-118); fp32 tokens
     against the oracle, all 12 blocks, both frames of a pair."""
@@ -752,7 +763,7 @@ def test_forward_tokens_strided_full_size():
     assert cfg.grid == 55 and cfg.tokens == 3025
     sd = weights.synthetic_state_dict(cfg, 2)
     frames = np.stack(synth.frame_pair(224, 20250901))
-    eng = _engine(cfg, config.ServoParams(dino_input_size=224, use_feature_binning=False), precision="fp32",
+    eng = _engine(cfg, config.ServoParams(dino_input_size=224, use_feature_binning=False), precision=exact,
                   max_pairs=1).load_state_dict(sd)
     got = eng.forward_tokens(frames).cpu()
     ref = _oracle_tokens(cfg, sd, frames)
@@ -766,10 +777,10 @@ def test_forward_tokens_strided_full_size():
 # is amplified by the exponential, so the 16-bit modes lose ~25x more here than on the near-uniform fixtures; fp16 / bf16 = 1 / 12.5,
 # the ratio of their roundings — rounding, not a defect) and the smallest token-wise cosine against the oracle's tokens (what the
 # correspondence consumes)
-STRESS_BARS = {"fp32": (1e-4, 0.999999), "fp16": (2e-2, 0.9999), "bf16": (2e-1, 0.995)}
+STRESS_BARS = {"fp32": (1e-4, 0.999999), "f16x2": (1e-4, 0.999999), "fp16": (2e-2, 0.9999), "bf16": (2e-1, 0.995)}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x2", "fp16", "bf16"])
 def test_forward_tokens_with_trained_like_statistics(precision):
     """Every other end-to-end fixture uses trunc-normal(0.02) weights: attention logits near 0, near-uniform softmax, no
     outlier channels.  This one (weights.trained_like_state_dict) has peaky softmax rows (entropy 0.9 - 2.5 nats, checked
@@ -823,9 +834,11 @@ def test_forward_tokens_with_trained_like_statistics(precision):
 # dtype to use; bf16's 99.8 % on the trunc-normal fixtures does not carry over.
 TRAINED_E2E = {   # measured (alone / in_flight3), MI355X:      sim_err            agree (min of nn_1, nn_2)   gap                drawn_same
     ("vitb16_224", "fp32"): dict(sim_err=1e-4, agree=1.0, gap=0.0, drawn_same=1.0),      # 2.8e-5 / 2.7e-5   1.0000                      0                  1.00
+    ("vitb16_224", "f16x2"): dict(sim_err=1e-4, agree=1.0, gap=0.0, drawn_same=1.0),     # the fp32 bars, unchanged
     ("vitb16_224", "fp16"): dict(sim_err=5e-2, agree=0.985, gap=1e-3, drawn_same=0.95),  # 3.2e-2 / 2.9e-2   0.9898                      2.8e-4             0.96
     ("vitb16_224", "bf16"): dict(sim_err=0.35, agree=0.88, gap=0.25, drawn_same=0.85),   # 2.7e-1 / 2.9e-1   0.9082 / 0.8980             2.2e-1             0.88
     ("vitl14_518", "fp32"): dict(sim_err=2e-4, agree=1.0, gap=0.0, drawn_same=1.0),      # 7.4e-5            1.0000                      0                  1.00
+    ("vitl14_518", "f16x2"): dict(sim_err=2e-4, agree=1.0, gap=0.0, drawn_same=1.0),     # the fp32 bars, unchanged
     ("vitl14_518", "fp16"): dict(sim_err=6e-2, agree=0.95, gap=1e-2, drawn_same=0.95),   # 4.1e-2            0.9591 / 0.9613             4.5e-3 / 3.3e-3    1.00 / 0.96
     ("vitl14_518", "bf16"): dict(sim_err=0.35, agree=0.75, gap=0.10, drawn_same=0.60),   # 2.9e-1 / 3.1e-1   0.7714 / 0.7736             7.9e-2             0.71 / 0.67
 }
@@ -952,7 +965,8 @@ def test_compute_velocity_16bit_many_tokens_full_size(key, precision, plan):
     assert _rel_l2(v, _law_on(cfg, params, want_sel, d1[want_sel], depth, k)["v_c"]) <= 1e-9 <= VC_TOL
 
 
-def test_batched_pairs_and_shared_goal():
+@pytest.mark.parametrize("exact", EXACT)
+def test_batched_pairs_and_shared_goal(exact):
     """B pairs in one call == B single calls (bit-identical), and des_shared == repeated I_des."""
     cfg = config.baseline_config("vits16_224")
     sd = weights.synthetic_state_dict(cfg, 0)
@@ -961,7 +975,7 @@ def test_batched_pairs_and_shared_goal():
     des = np.stack([p[0] for p in pairs])
     cur = np.stack([p[1] for p in pairs])
     depth = np.stack([synth.depth_pattern()] * 3)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=3, max_rows=196).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=3, max_rows=196).load_state_dict(sd)
     vb, sb = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
     detb = eng.last_details(3)
     for i in range(3):
@@ -974,8 +988,9 @@ def test_batched_pairs_and_shared_goal():
     assert torch.equal(vs, vr) and torch.equal(ss, sr_)
 
 
+@pytest.mark.parametrize("exact", EXACT)
 @pytest.mark.parametrize("plan", PLANS)
-def test_rig_of_8_vitb16_pairs_in_one_call(plan):
+def test_rig_of_8_vitb16_pairs_in_one_call(plan, exact):
     """BASELINE.json configs[3] on one GPU: 8 ViT-B/16 224² pairs in ONE call (what one rank of the rig runs when the
     rig is smaller than the camera count).  Against the reference-generated fixture: arg-max tables bit-exact and v_c
     <= 1e-9 for every pair given the reference's draw (pair 0 is the headline fixture's pair); against 8 single calls:
@@ -991,7 +1006,7 @@ def test_rig_of_8_vitb16_pairs_in_one_call(plan):
     cur = np.stack([p[1] for p in pairs])
     depth = np.stack([synth.depth_pattern()] * 8)
     sels = [_ids(blob[f"pair{i}/points1"], cfg.grid) for i in range(8)]
-    eng = _PlanRunner(plan, cfg, params, sd, "fp32", max_pairs=8)
+    eng = _PlanRunner(plan, cfg, params, sd, exact, max_pairs=8)
     vb, sb = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=sels)
     detb = eng.last_details(8)
     vb = vb.cpu().numpy()
@@ -1035,7 +1050,8 @@ def test_num_pairs_is_a_per_call_argument():
         eng.compute_velocity(cur, des, depth, p24.intrinsics(), mode=_lib.SELECT_ORDER, selection=order, num_pairs=49)
 
 
-def test_rotation_compensation_scores_match_the_reference():
+@pytest.mark.parametrize("exact", EXACT)
+def test_rotation_compensation_scores_match_the_reference(exact):
     """find_and_set_best_pose (vitvs_v2.py:1151-1189): 4 views against one goal, num_pairs = 48, score = mean selected
     similarity.  Given the reference's draws (fixture generated by the reference's find_correspondences_batch), the four
     device scores equal the reference's; Controller.best_rotation (own draws, one batch, shared goal forward) picks the
@@ -1047,7 +1063,7 @@ def test_rotation_compensation_scores_match_the_reference():
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     views = np.stack([np.rot90(cur, int(k)).copy() for k in blob["rot90_k"]])
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=4).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=4).load_state_dict(sd)
     k = int(blob["num_pairs"])
     sels = [_ids(blob[f"view{i}/points1"], cfg.grid) for i in range(4)]
     depth = np.zeros((4, params.v_max, params.u_max), np.uint16)
@@ -1206,7 +1222,8 @@ def test_host_pointer_entry_point_matches_device_entry_point():
 
 
 # ----------------------------------------------------------------------------- host mirror of the reference interface
-def test_controller_adapter_reproduces_reference_update():
+@pytest.mark.parametrize("exact", EXACT)
+def test_controller_adapter_reproduces_reference_update(exact):
     """Controller.detect_features()/ibvs() with the reference's RNG procedure == the golden v_c (drop-in check)."""
     from vitvs_amd import servo
     key = "vits16_224"
@@ -1216,7 +1233,7 @@ def test_controller_adapter_reproduces_reference_update():
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=4).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=4).load_state_dict(sd)
     ctl = servo.Controller(eng, goal_image=des, selection="reference")
     assert ctl.detect_features() == (None, None)          # no image yet
     ctl.image_callback_rgb(cur)
@@ -1242,7 +1259,8 @@ def test_controller_adapter_reproduces_reference_update():
     assert best == 1 and len(scores) == 4
 
 
-def test_controller_with_camera_resolution_frames_and_reference_selection():
+@pytest.mark.parametrize("exact", EXACT)
+def test_controller_with_camera_resolution_frames_and_reference_selection(exact):
     """640x480 camera frames (the normal case): the adapter resizes on the device (a CUDA tensor reaches the reference-
     selection path) and the update equals the one computed from host-side PIL-identical resizes."""
     from vitvs_amd import servo
@@ -1250,7 +1268,7 @@ def test_controller_with_camera_resolution_frames_and_reference_selection():
     cfg = config.baseline_config("vits16_224")
     sd = weights.synthetic_state_dict(cfg, 0)
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=1).load_state_dict(sd)
     rng = np.random.default_rng(77)
     goal = synth.texture(640, 5)[:480]                                  # 480 x 640 x 3
     cam = synth.warp_similarity(goal, shift=(14.0, -8.0), rot_deg=3.0, scale=1.02, seed=6)
@@ -1299,7 +1317,7 @@ def test_controller_failure_counter_raises_like_the_reference():
         servo.compute_velocity = orig
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2), ("f16x2", 2e-5)])
 @pytest.mark.parametrize("layerscale", [False, True])
 def test_extract_descriptors_facets(precision, tol, layerscale):
     """The extractor's descriptor surface (dinov2_extractor.py:193-217, 313-337): every facet, plain (layout d*H + h, cls
@@ -1373,7 +1391,7 @@ def test_extract_saliency_maps(precision, stride):
 
 
 # ----------------------------------------------------------------------------------- size-independent properties
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
 def test_update_is_bit_reproducible_run_to_run(precision):
     """The path uses atomicMax on packed (similarity, index) keys and fixed-order split-K sums: two runs of the same
     update on the headline configuration must agree bit for bit (indices, similarities, v_c)."""
@@ -1415,12 +1433,13 @@ def test_many_token_updates_alternating_inputs_are_bit_reproducible():
     assert not np.array_equal(first[0][1], first[1][1])
 
 
-def test_swapping_the_frames_swaps_the_nearest_neighbour_tables():
+@pytest.mark.parametrize("exact", EXACT)
+def test_swapping_the_frames_swaps_the_nearest_neighbour_tables(exact):
     """S(cur, des) = S(des, cur)^T: row arg-maxes of one are column arg-maxes of the other (full-size ViT-B/16 pair,
     fp32; the fixture's margins rule out ties)."""
     cfg = config.baseline_config("vitb16_224")
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    eng = _engine(cfg, params, precision=exact, max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
     des, cur = synth.frame_pair(cfg.img_size, synth.ACCEPTED_FRAME_SEEDS["vitb16_224"])
     d = eng.extract_descriptors(np.stack([des, cur]))[:, 0]
     nn1_a, nn2_a, sim_a = (t.cpu() for t in eng.correspond(d[0], d[1]))
@@ -1433,11 +1452,12 @@ def test_swapping_the_frames_swaps_the_nearest_neighbour_tables():
     assert torch.equal(smat.argmax(dim=0).cpu().to(torch.int32), nn2_a.to(torch.int32))
 
 
-def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
+@pytest.mark.parametrize("exact", EXACT)
+def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity(exact):
     """mean(sim_1) > 0.99 (vitvs_v2.py:84-101): identical points on both sides, e = 0, so v_c = 0 exactly."""
     cfg = config.baseline_config("vits16_224")
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
+    eng = _engine(cfg, params, precision=exact, max_pairs=1).load_state_dict(weights.synthetic_state_dict(cfg, 0))
     des, _ = synth.frame_pair(cfg.img_size, 99)
     v, st = eng.compute_velocity(des, des, synth.depth_pattern(), params.intrinsics(), mode=_lib.SELECT_ORDER,
                                  selection=torch.randperm(cfg.tokens).to(torch.int32)[None])
@@ -1458,7 +1478,8 @@ def test_identical_frames_take_the_same_image_shortcut_and_give_zero_velocity():
     assert np.all(v.cpu().numpy() == 0.0)
 
 
-def test_dense_correspondence_and_interaction_matrix_at_3136_tokens():
+@pytest.mark.parametrize("exact", EXACT)
+def test_dense_correspondence_and_interaction_matrix_at_3136_tokens(exact):
     """BASELINE configs[2]: DINO ViT-B/8 448² — every mutual nearest neighbour of the 3136 tokens enters L_e (thousands of
     rows: the interaction matrix lives in the global workspace and the pseudo-inverse runs as one-sided Jacobi SVD).
     The law is checked against the oracle GIVEN the device's own nearest-neighbour tables (their parity with the oracle's
@@ -1469,7 +1490,7 @@ def test_dense_correspondence_and_interaction_matrix_at_3136_tokens():
     sd = weights.synthetic_state_dict(cfg, int(blob["weight_seed"]))
     des, cur = synth.frame_pair(cfg.img_size, int(blob["frame_seed"]))
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
     depth = synth.depth_pattern()
     v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
     det = eng.last_details(1)
@@ -1487,14 +1508,15 @@ def test_dense_correspondence_and_interaction_matrix_at_3136_tokens():
     assert _rel_l2(v.cpu().numpy()[0], ref["v_c"]) <= 1e-9
 
 
-def test_argmax_parity_over_a_sweep_of_frame_pairs():
+@pytest.mark.parametrize("exact", EXACT)
+def test_argmax_parity_over_a_sweep_of_frame_pairs(exact):
     """Beyond the accepted fixtures: 8 arbitrary frame pairs (ViT-S/16 224², fp32), device arg-maxes against the oracle's
     similarity matrix — every disagreement must be a <= 2e-5 tie there — and the dense control law given the device's
     own tables within 1e-9 of the oracle's."""
     cfg = config.baseline_config("vits16_224")
     sd = weights.synthetic_state_dict(cfg, 0)
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
+    eng = _engine(cfg, params, precision=exact, max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
     depth = synth.depth_pattern()
     g = cfg.grid
     exact = 0

@@ -42,10 +42,9 @@ def test_attention_matches_vendored_dinov2_attention():
     assert float((ref - mine).abs().max()) < 5e-6
 
 
-def test_forward_matches_hf_vit():
-    transformers = pytest.importorskip("transformers")
-    cfg = _tiny_cfg(False)
-    sd = weights.synthetic_state_dict(cfg, 1)
+def _hf_vit_hidden_states(cfg, sd, frames):
+    """HF ViTModel built from a local config with the oracle's weights: (model, preprocessed input, hidden states)."""
+    import transformers
     hf_cfg = transformers.ViTConfig(hidden_size=cfg.dim, num_hidden_layers=cfg.blocks_run,
                                     num_attention_heads=cfg.heads, intermediate_size=cfg.hidden,
                                     image_size=cfg.img_size, patch_size=cfg.patch, layer_norm_eps=cfg.ln_eps,
@@ -75,10 +74,18 @@ def test_forward_matches_hf_vit():
     missing, unexpected = model.load_state_dict(m, strict=False)
     assert not [k for k in missing if not k.startswith("layernorm.")], missing
     assert not unexpected
-    frames = _frames(cfg)
     x = vit_ref.preprocess_u8(frames, cfg.mean, cfg.std)
     with torch.no_grad():
         hs = model(pixel_values=x, output_hidden_states=True).hidden_states
+    return model, x, hs
+
+
+def test_forward_matches_hf_vit():
+    pytest.importorskip("transformers")
+    cfg = _tiny_cfg(False)
+    sd = weights.synthetic_state_dict(cfg, 1)
+    frames = _frames(cfg)
+    model, x, hs = _hf_vit_hidden_states(cfg, sd, frames)
     mine = _oracle_tokens(cfg, sd, frames, return_all=True)
     assert len(hs) == len(mine)
     for a, b in zip(hs, mine):
@@ -100,10 +107,27 @@ def test_forward_matches_hf_vit():
         assert float((sal - want).abs().max()) < 1e-4
 
 
-def test_forward_matches_hf_dinov2_layerscale():
-    transformers = pytest.importorskip("transformers")
-    cfg = _tiny_cfg(True)
-    sd = weights.synthetic_state_dict(cfg, 2)
+def test_forward_matches_hf_vit_at_vitb16_width():
+    """The same witness at the headline model's dimensions (ViT-B/16 224²: 768 wide, 12 heads, 3072 hidden, 197 tokens; two
+    blocks suffice — every block is the same arithmetic): patch embedding, cls / pos-embed, attention and MLP at full width."""
+    pytest.importorskip("transformers")
+    cfg = dataclasses.replace(config.baseline_config("vitb16_224"), depth=2, layer=1)
+    sd = weights.synthetic_state_dict(cfg, 4)
+    frames = _frames(cfg, n=2, seed=3)
+    _, _, hs = _hf_vit_hidden_states(cfg, sd, frames)
+    mine = _oracle_tokens(cfg, sd, frames, return_all=True)
+    assert len(hs) == len(mine) == 3
+    for a, b in zip(hs, mine):
+        assert a.shape == b.shape == (2, 197, 768)
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def _hf_dinov2_hidden_states(cfg, sd, frames):
+    """HF Dinov2Model from a local config with the oracle's weights.  The position embedding handed over is the oracle's
+    RESAMPLED one (HF's own interpolation differs from the reference's "+0.1" scale-factor form, dinov2_extractor.py:94-118;
+    the oracle's resample is pinned to the reference's ``_fix_pos_enc`` by tests/golden/extractor_pieces.npz), so HF does no
+    interpolation of its own and witnesses everything else."""
+    import transformers
     hf_cfg = transformers.Dinov2Config(hidden_size=cfg.dim, num_hidden_layers=cfg.blocks_run,
                                        num_attention_heads=cfg.heads, mlp_ratio=4, image_size=cfg.img_size,
                                        patch_size=cfg.patch, layer_norm_eps=cfg.ln_eps, hidden_act="gelu",
@@ -112,7 +136,7 @@ def test_forward_matches_hf_dinov2_layerscale():
                                        drop_path_rate=0.0)
     model = transformers.Dinov2Model(hf_cfg).eval()
     own = model.state_dict()
-    m = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": sd["pos_embed"],
+    m = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": vit_ref.resample_pos_embed(sd["pos_embed"], cfg.grid),
          "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
          "embeddings.mask_token": own["embeddings.mask_token"]}
@@ -138,12 +162,36 @@ def test_forward_matches_hf_dinov2_layerscale():
     missing, unexpected = model.load_state_dict(m, strict=False)
     assert not [k for k in missing if not k.startswith("layernorm.")], missing
     assert not unexpected
-    frames = _frames(cfg)
     x = vit_ref.preprocess_u8(frames, cfg.mean, cfg.std)
     with torch.no_grad():
-        hs = model(pixel_values=x, output_hidden_states=True).hidden_states
+        return model(pixel_values=x, output_hidden_states=True).hidden_states
+
+
+def test_forward_matches_hf_dinov2_layerscale():
+    pytest.importorskip("transformers")
+    cfg = _tiny_cfg(True)
+    sd = weights.synthetic_state_dict(cfg, 2)
+    frames = _frames(cfg)
+    hs = _hf_dinov2_hidden_states(cfg, sd, frames)
     mine = _oracle_tokens(cfg, sd, frames, return_all=True)
     for a, b in zip(hs, mine):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_forward_matches_hf_dinov2_at_vits14_308_width():
+    """The reference's shipped configuration (config.yaml: DINOv2 ViT-S/14 at 308²): 384 wide, 6 heads, LayerScale gains != 1,
+    the stored 37 x 37 position grid resampled to 22 x 22 (485 tokens); three blocks at full width."""
+    pytest.importorskip("transformers")
+    cfg = dataclasses.replace(config.baseline_config("vits14_308"), depth=3, layer=2)
+    assert cfg.layerscale and cfg.native_grid == 37 and cfg.grid == 22
+    sd = weights.synthetic_state_dict(cfg, 6)
+    assert float((sd["blocks.0.ls1.gamma"] - 1).abs().max()) > 0.1           # gains that would show a misplaced LayerScale
+    frames = _frames(cfg, n=2, seed=5)
+    hs = _hf_dinov2_hidden_states(cfg, sd, frames)
+    mine = _oracle_tokens(cfg, sd, frames, return_all=True)
+    assert len(hs) == len(mine) == 4
+    for a, b in zip(hs, mine):
+        assert a.shape == b.shape == (2, 485, 384)
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 

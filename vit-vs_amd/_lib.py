@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VITVS_LIB") or os.path.join(_HERE, "libvitvs_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 2
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F16X2 = 0, 1, 2, 3
 STATUS_OK, STATUS_NO_CORRESPONDENCE, STATUS_TOO_FEW, STATUS_NO_DEPTH = 0, 1, 2, 3
 SELECT_EXPLICIT, SELECT_ORDER, SELECT_DENSE = 0, 1, 2
 
@@ -75,6 +75,7 @@ PROTOTYPES = {
     "vitvs_op_attention_q": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_splitk_slices": (_I, [_I, _I, _I, _I]),
     "vitvs_op_plan_in_flight": (_I, [_I]),
+    "vitvs_op_weight_exponent": (_I, [_I]),
     "vitvs_op_linear_tile": (_I, [_I, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_partial": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_residual_ln": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),

@@ -22,6 +22,7 @@ static thread_local std::string g_last_error;
 thread_local LaunchTiming g_launch_timing;
 thread_local int g_current_device = -1;
 thread_local int g_updates_in_flight = 1;
+static thread_local int g_op_wexp = 0;   // vitvs_op_weight_exponent: the 2^e the f16x2 weights of the operator hooks carry
 
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     char buf[512];
@@ -30,7 +31,9 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
     return -100 - (int)e;
 }
 
-static inline Precision to_prec(int32_t p) { return p == VITVS_F32 ? PREC_F32 : (p == VITVS_F16 ? PREC_F16 : PREC_BF16); }
+static inline Precision to_prec(int32_t p) {
+    return p == VITVS_F32 ? PREC_F32 : (p == VITVS_F16 ? PREC_F16 : (p == VITVS_F16X2 ? PREC_X2 : PREC_BF16));
+}
 
 static inline uint16_t f32_to_f16_host(float f) {   // round to nearest even, as the device's v_cvt_f16_f32
     const _Float16 hval = (_Float16)f;
@@ -51,6 +54,7 @@ struct Block {
     float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
     float *qkvb = nullptr, *projb = nullptr, *fc1b = nullptr, *fc2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
     void *qkvw = nullptr, *projw = nullptr, *fc1w = nullptr, *fc2w = nullptr;
+    int qkve = 0, proje = 0, fc1e = 0, fc2e = 0;   // f16x2: each matrix is stored times 2^e (upload_matrix)
 };
 
 // Device memory of one set of weights.  Held through a shared_ptr by the handle that uploaded it AND by every handle that
@@ -93,6 +97,7 @@ struct vitvs_handle {
     // weights
     std::vector<Block> blk;
     void* pe_w = nullptr;
+    int pe_e = 0;
     float *pe_b = nullptr, *cls = nullptr, *pos = nullptr;
     // activations
     void *Ape = nullptr, *xn = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
@@ -108,11 +113,10 @@ struct vitvs_handle {
     float* sim1 = nullptr;
     double *feat = nullptr, *Lws = nullptr;
     int last_pairs = 0, last_T = 0;
-    // staging for the host-pointer API
+    // device copies of the frames a host-pointer call hands over (filled from the pinned block, HostStage below), and the
+    // graph replays' own copy of the selection
     uint8_t *st_cur = nullptr, *st_des = nullptr;
-    uint16_t* st_depth = nullptr;
-    double *st_K = nullptr, *st_vc = nullptr;
-    int32_t *st_sel = nullptr, *st_nsel = nullptr, *st_status = nullptr;
+    int32_t *st_sel = nullptr, *st_nsel = nullptr;
     // per-kernel-class timing (HIP events on the launch stream), see vitvs_timing_*
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -131,6 +135,24 @@ struct vitvs_handle {
     bool borrowed = false;    // weights belong to another handle (vitvs_share_weights): never uploaded to, never freed here
     int in_flight = 1;        // vitvs_set_option "in_flight": updates expected to run beside this handle's (tile plan hint)
     int goal_frames = 0;      // goal frames whose tokens / descriptors are cached in rows [0, goal_frames) (vitvs_set_goal_dev)
+    // Host-pointer entry points (vitvs_compute_velocity, vitvs_set_goal): ONE block of pinned, device-visible host memory,
+    // allocated on first use.  Caller buffers are copied into it with memcpy; the frames then reach device memory through a
+    // short copy launch on the update's own stream (launch_copy16), the intrinsics / visiting order / depth image are read by
+    // the law's kernel in place (it touches <= max_rows depth pixels), and v_c / status / the feature rows are written back
+    // into it by the device — no copy-engine command, no pageable transfer, one wait at the end.
+    struct HostStage {
+        unsigned char* base = nullptr;
+        size_t frame_cap = 0;     // bytes per staged frame
+        uint8_t *cur = nullptr, *des = nullptr;
+        uint16_t* depth = nullptr;
+        double *K = nullptr, *vc = nullptr;
+        int32_t *sel = nullptr, *nsel = nullptr, *status = nullptr;
+        unsigned char* det = nullptr;   // image of the device's detail block (info | s_uv | feat) of the last host-pointer call
+    } hs;
+    hipStream_t host_stream = nullptr;
+    bool details_pinned = false;        // hs.det holds the last call's info / s_uv / feat (vitvs_last_details serves them from there)
+    unsigned char* det_block = nullptr; // device: info [P][8] i32 | s_uv [P][R][4] i32 | feat [P][R][4] f64, one allocation
+    size_t det_bytes = 0;
 };
 
 namespace {
@@ -191,8 +213,12 @@ int upload_f32(vitvs_handle* h, float** dst, const float* src, size_t n) {
     return 0;
 }
 
-// matrix [rows][cols] fp32 host -> device in the handle's precision, row stride `ld` (zero padded)
-int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, size_t cols, size_t ld) {
+// matrix [rows][cols] fp32 host -> device in the handle's precision, row stride `ld` (zero padded).
+// f16x2 (PREC_X2): every element becomes an fp16 pair hi = fp16(w 2^e), lo = fp16(w 2^e - hi), rows laid out as [hi of 32
+// columns | lo of the same 32] per 64 fp16 (csrc/common.h); e is the power of two that puts the matrix's largest magnitude in
+// [2^12, 2^13), so the lo halves of all but negligible weights are NORMAL fp16 numbers (22 significant bits) and nothing
+// overflows; the GEMM multiplies its sums by 2^-e (*wexp, 0 .. 31).
+int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, size_t cols, size_t ld, int* wexp = nullptr) {
     const size_t es = elem_size(h->prec);
     if (!*dst) {
         unsigned char* p = nullptr;
@@ -201,6 +227,31 @@ int upload_matrix(vitvs_handle* h, void** dst, const float* src, size_t rows, si
         *dst = p;
     }
     std::vector<unsigned char> tmp(rows * ld * es, 0);
+    if (h->prec == PREC_X2) {
+        if (ld % 32 != 0) return set_err(h, -6, "f16x2 rows are multiples of 32 columns");
+        float amax = 0.f;
+        for (size_t i = 0; i < rows * cols; ++i) amax = std::max(amax, fabsf(src[i]));
+        int e = 0;
+        if (amax > 0.f && std::isfinite(amax)) {
+            int ex = 0;
+            (void)frexpf(amax, &ex);                       // amax = f 2^ex, f in [0.5, 1)
+            e = std::min(31, std::max(0, 13 - ex));        // amax 2^e in [2^12, 2^13)
+        }
+        if (wexp) *wexp = e;
+        const float sc = ldexpf(1.0f, e);
+        uint16_t* d = reinterpret_cast<uint16_t*>(tmp.data());
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) {
+                const float v = src[r * cols + c] * sc;    // exact (power of two)
+                const float vc = std::min(65504.0f, std::max(-65504.0f, v));
+                const _Float16 hi = (_Float16)vc;
+                const size_t at = r * 2 * ld + ((c >> 5) << 6) + (c & 31);
+                d[at] = f32_to_f16_host((float)hi);
+                d[at + 32] = f32_to_f16_host(v - (float)hi);
+            }
+        VITVS_HIP_CHECK(hipMemcpy(*dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+        return 0;
+    }
     for (size_t r = 0; r < rows; ++r) {
         if (h->prec == PREC_F32) {
             memcpy(tmp.data() + r * ld * 4, src + r * cols, cols * 4);
@@ -221,7 +272,7 @@ int check_cfg(const vitvs_config* c, std::string& why) {
     if (c->patch <= 0 || c->stride <= 0 || c->img_size < c->patch) { why = "bad patch/stride/img_size"; return -1; }
     if ((c->img_size - c->patch) % c->stride != 0) { why = "img_size - patch must be a multiple of stride"; return -1; }
     if (c->blocks <= 0) { why = "blocks must be >= 1"; return -1; }
-    if (c->precision != VITVS_F32 && c->precision != VITVS_BF16 && c->precision != VITVS_F16) { why = "unknown precision"; return -1; }
+    if (c->precision != VITVS_F32 && c->precision != VITVS_BF16 && c->precision != VITVS_F16 && c->precision != VITVS_F16X2) { why = "unknown precision"; return -1; }
     if (c->max_pairs <= 0 || c->num_pairs <= 0 || c->max_rows < c->num_pairs) { why = "bad capacity"; return -1; }
     if (c->u_max <= 0 || c->v_max <= 0) { why = "bad camera resolution"; return -1; }
     if (c->dim != 128 && c->dim != 256 && c->dim != 384 && c->dim != 768 && c->dim != 1024) {
@@ -317,7 +368,7 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
     // fc2 (split-K partials) -> [residual + norm1 of block i+1].
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PATCH_EMBED, st);
         rc = launch_linear_partial(h->prec, cx[k].Ape, h->pe_w, cx[k].part, cx[k].cnt * h->T, D, h->Kp,
-                                   splitk_slices(h->prec, cx[k].cnt * h->T, D, h->Kp), st); }
+                                   splitk_slices(h->prec, cx[k].cnt * h->T, D, h->Kp), st, h->pe_e); }
     for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_LAYERNORM, st);
         rc = launch_embed_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].cnt * h->T, D, h->Kp), h->pe_b, h->pos,
                              h->cls, h->blk[0].n1w, h->blk[0].n1b, cx[k].xn, cx[k].cnt, h->T, D, c.ln_eps, st); }
@@ -325,20 +376,20 @@ int forward_lockstep(vitvs_handle* h, ChainCtx* cx, int n, hipStream_t st) {
         const Block& b = h->blk[i];
         const Block* nx = (i + 1 < c.blocks) ? &h->blk[i + 1] : nullptr;
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_QKV, st);
-            rc = launch_linear(h->prec, cx[k].xn, b.qkvw, b.qkvb, cx[k].qkv, cx[k].M, 3 * D, D, 0, st); }
+            rc = launch_linear(h->prec, cx[k].xn, b.qkvw, b.qkvb, cx[k].qkv, cx[k].M, 3 * D, D, 0, st, b.qkve); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_ATTENTION, st);
-            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st, &h->attn_ws, h->prec != PREC_F32); }
+            rc = launch_attention(h->prec, cx[k].qkv, cx[k].attn, cx[k].cnt, h->N, c.heads, st, &h->attn_ws, plain16(h->prec)); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_PROJ, st);
             rc = launch_linear_partial(h->prec, cx[k].attn, b.projw, cx[k].part, cx[k].M, D, D,
-                                       splitk_slices(h->prec, cx[k].M, D, D), st); }
+                                       splitk_slices(h->prec, cx[k].M, D, D), st, b.proje); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_RESIDUAL_LN, st);
             rc = launch_residual_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].M, D, D), b.projb, b.ls1,
                                     b.n2w, b.n2b, cx[k].xn, cx[k].M, D, c.ln_eps, st); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_FC1, st);
-            rc = launch_linear(h->prec, cx[k].xn, b.fc1w, b.fc1b, cx[k].hid, cx[k].M, h->hidden, D, 1, st); }
+            rc = launch_linear(h->prec, cx[k].xn, b.fc1w, b.fc1b, cx[k].hid, cx[k].M, h->hidden, D, 1, st, b.fc1e); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_FC2, st);
             rc = launch_linear_partial(h->prec, cx[k].hid, b.fc2w, cx[k].part, cx[k].M, D, h->hidden,
-                                       splitk_slices(h->prec, cx[k].M, D, h->hidden), st); }
+                                       splitk_slices(h->prec, cx[k].M, D, h->hidden), st, b.fc2e); }
         for (int k = 0; k < n && !rc; ++k) { Span sp(h, KC_RESIDUAL_LN, st);
             rc = launch_residual_ln(h->prec, cx[k].x, cx[k].part, splitk_slices(h->prec, cx[k].M, D, h->hidden), b.fc2b,
                                     b.ls2, nx ? nx->n1w : nullptr, nx ? nx->n1b : nullptr, cx[k].xn, cx[k].M, D, c.ln_eps, st,
@@ -433,6 +484,47 @@ int run_servo(vitvs_handle* h, int n_pairs, int T, const uint16_t* Z, const doub
     return 0;
 }
 
+// The pinned staging block of the host-pointer entry points, sized for the handle's capacity and current frame geometry.
+int ensure_host_stage(vitvs_handle* h) {
+    const vitvs_config& c = h->cfg;
+    if (h->hs.base && h->hs.frame_cap >= h->staged_frame_bytes) return 0;
+    if (h->hs.base) {
+        VITVS_HIP_CHECK(hipDeviceSynchronize());            // a launch may still read the previous block
+        (void)hipHostFree(h->hs.base);
+        h->hs = vitvs_handle::HostStage{};
+        h->details_pinned = false;
+    }
+    const size_t P = c.max_pairs, fb = (h->staged_frame_bytes + 255) & ~(size_t)255;
+    const size_t sel_cap = P * (size_t)(h->T > c.max_rows ? h->T : c.max_rows);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_cur = 0, o_des = o_cur + P * fb, o_depth = o_des + P * fb, o_K = o_depth + up(P * (size_t)c.u_max * c.v_max * 2),
+                 o_vc = o_K + up(P * 32), o_sel = o_vc + up(P * 48), o_nsel = o_sel + up(sel_cap * 4), o_st = o_nsel + up(P * 4),
+                 o_det = o_st + up(P * 4), total = o_det + up(h->det_bytes) + 256;
+    void* p = nullptr;
+    VITVS_HIP_CHECK(hipHostMalloc(&p, total, hipHostMallocDefault));
+    memset(p, 0, total);
+    unsigned char* b = static_cast<unsigned char*>(p);
+    h->hs.base = b; h->hs.frame_cap = h->staged_frame_bytes;
+    h->hs.cur = b + o_cur; h->hs.des = b + o_des; h->hs.depth = reinterpret_cast<uint16_t*>(b + o_depth);
+    h->hs.K = reinterpret_cast<double*>(b + o_K); h->hs.vc = reinterpret_cast<double*>(b + o_vc);
+    h->hs.sel = reinterpret_cast<int32_t*>(b + o_sel); h->hs.nsel = reinterpret_cast<int32_t*>(b + o_nsel);
+    h->hs.status = reinterpret_cast<int32_t*>(b + o_st); h->hs.det = b + o_det;
+    if (!h->host_stream) VITVS_HIP_CHECK(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
+    return 0;
+}
+
+// Wait for a stream the way a control loop wants it: poll (the update takes ~0.5 ms; a blocking wait adds its wake-up
+// latency to every update), then hand over to the blocking wait if the device is far behind.
+int wait_stream(hipStream_t st) {
+    for (int i = 0; i < 200000; ++i) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery", __FILE__, __LINE__);
+    }
+    VITVS_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -510,7 +602,7 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     if (!rc && cfg->binned && (size_t)cfg->max_pairs * h->T * h->T * 4 <= (8ull << 30))
         rc = dev_alloc(h, &h->gram_ws, (size_t)cfg->max_pairs * h->T * h->T);
     // 16-bit modes, >= 1024 tokens: the Gram runs on the f16 matrix cores from a hi / lo split of the descriptors (correspond.hip)
-    if (!rc && !h->gram_ws && h->prec != PREC_F32 && h->T >= 1024 && h->Dp % 64 == 0 &&
+    if (!rc && !h->gram_ws && plain16(h->prec) && h->T >= 1024 && h->Dp % 64 == 0 &&
         gram_split_elems(h->n_img_max, h->T, h->Dp) * 2 < (1ull << 32))
         rc = dev_alloc(h, &h->dh, gram_split_elems(h->n_img_max, h->T, h->Dp));
     if (!rc) rc = dev_alloc(h, &h->sq, (size_t)h->n_img_max * h->T);
@@ -522,22 +614,22 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     if (!rc) rc = dev_alloc(h, &h->nn2, h->best_elems);
     if (!rc) rc = dev_alloc(h, &h->sim1, h->best_elems);
     const size_t P = cfg->max_pairs, R = cfg->max_rows;
-    if (!rc) rc = dev_alloc(h, &h->info, P * 8);
+    h->det_bytes = P * 32 + P * R * 16 + P * R * 32;
+    if (!rc) rc = dev_alloc(h, &h->det_block, h->det_bytes);
+    if (!rc) {
+        h->info = reinterpret_cast<int32_t*>(h->det_block);
+        h->s_uv = reinterpret_cast<int32_t*>(h->det_block + P * 32);
+        h->feat = reinterpret_cast<double*>(h->det_block + P * 32 + P * R * 16);
+    }
     if (!rc) rc = dev_alloc(h, &h->sel_out, P * R);
-    if (!rc) rc = dev_alloc(h, &h->s_uv, P * R * 4);
-    if (!rc) rc = dev_alloc(h, &h->feat, P * R * 4);
     if (!rc) rc = dev_alloc(h, &h->Lws, P * 7 * 2 * R);
     const size_t img_bytes = (size_t)cfg->img_size * cfg->img_size * 3;
     h->staged_frame_bytes = img_bytes;
     if (!rc) rc = dev_alloc(h, &h->st_cur, P * img_bytes);
     if (!rc) rc = dev_alloc(h, &h->st_des, P * img_bytes);
-    if (!rc) rc = dev_alloc(h, &h->st_depth, P * (size_t)cfg->u_max * cfg->v_max);
-    if (!rc) rc = dev_alloc(h, &h->st_K, P * 4);
-    if (!rc) rc = dev_alloc(h, &h->st_vc, P * 6);
     const size_t sel_cap = P * (size_t)(h->T > cfg->max_rows ? h->T : cfg->max_rows);
     if (!rc) rc = dev_alloc(h, &h->st_sel, sel_cap);
     if (!rc) rc = dev_alloc(h, &h->st_nsel, P);
-    if (!rc) rc = dev_alloc(h, &h->st_status, P);
     if (rc) {
         std::string msg = g_last_error;
         vitvs_destroy(h);
@@ -554,6 +646,8 @@ void vitvs_destroy(vitvs_handle* h) {
     drop_graphs(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->hs.base) (void)hipHostFree(h->hs.base);
+    if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     delete h;
 }
 
@@ -573,7 +667,7 @@ int vitvs_share_weights(vitvs_handle* h, const vitvs_handle* src) {
         drop_graphs(h);
     }
     h->blk = src->blk;
-    h->pe_w = src->pe_w; h->pe_b = src->pe_b; h->cls = src->cls; h->pos = src->pos;
+    h->pe_w = src->pe_w; h->pe_e = src->pe_e; h->pe_b = src->pe_b; h->cls = src->cls; h->pos = src->pos;
     h->have = src->have;
     h->wstore = src->wstore;                    // shared ownership: the weights outlive whichever of the two is destroyed first
     h->ready = true;
@@ -596,7 +690,7 @@ int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64
     if (nm == "patch_embed.proj.weight") {
         const size_t pk = 3 * (size_t)c.patch * c.patch;
         if ((rc = want(D * pk))) return rc;
-        rc = upload_matrix(h, &h->pe_w, data, D, pk, h->Kp);
+        rc = upload_matrix(h, &h->pe_w, data, D, pk, h->Kp, &h->pe_e);
     } else if (nm == "patch_embed.proj.bias") {
         if ((rc = want(D))) return rc;
         rc = upload_f32(h, &h->pe_b, data, D);
@@ -626,18 +720,18 @@ int vitvs_set_tensor(vitvs_handle* h, const char* name, const float* data, int64
             if ((rc = want(n))) return rc;
             std::vector<float> scaled;
             const float* src = data;
-            if (h->prec != PREC_F32) {
+            if (plain16(h->prec)) {
                 scaled.assign(data, data + n);
                 for (size_t i = 0; i < nq; ++i) scaled[i] *= kAttnQScale;
                 src = scaled.data();
             }
-            rc = w ? upload_matrix(h, &b.qkvw, src, 3 * D, D, D) : upload_f32(h, &b.qkvb, src, 3 * D);
+            rc = w ? upload_matrix(h, &b.qkvw, src, 3 * D, D, D, &b.qkve) : upload_f32(h, &b.qkvb, src, 3 * D);
         }
-        else if (leaf == "attn.proj.weight") { if ((rc = want(D * D))) return rc; rc = upload_matrix(h, &b.projw, data, D, D, D); }
+        else if (leaf == "attn.proj.weight") { if ((rc = want(D * D))) return rc; rc = upload_matrix(h, &b.projw, data, D, D, D, &b.proje); }
         else if (leaf == "attn.proj.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.projb, data, D); }
-        else if (leaf == "mlp.fc1.weight") { if ((rc = want(H4 * D))) return rc; rc = upload_matrix(h, &b.fc1w, data, H4, D, D); }
+        else if (leaf == "mlp.fc1.weight") { if ((rc = want(H4 * D))) return rc; rc = upload_matrix(h, &b.fc1w, data, H4, D, D, &b.fc1e); }
         else if (leaf == "mlp.fc1.bias") { if ((rc = want(H4))) return rc; rc = upload_f32(h, &b.fc1b, data, H4); }
-        else if (leaf == "mlp.fc2.weight") { if ((rc = want(D * H4))) return rc; rc = upload_matrix(h, &b.fc2w, data, D, H4, H4); }
+        else if (leaf == "mlp.fc2.weight") { if ((rc = want(D * H4))) return rc; rc = upload_matrix(h, &b.fc2w, data, D, H4, H4, &b.fc2e); }
         else if (leaf == "mlp.fc2.bias") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.fc2b, data, D); }
         else if (leaf == "ls1.gamma") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.ls1, data, D); }
         else if (leaf == "ls2.gamma") { if ((rc = want(D))) return rc; rc = upload_f32(h, &b.ls2, data, D); }
@@ -813,7 +907,7 @@ int vitvs_extract_descriptors_ex_dev(vitvs_handle* h, int32_t n_frames, const ui
         // q / k / v of blocks[layer] in the reference's layout (index d * H + h), fp32, WITH the cls row, over the residual
         // stream's own buffer (the forward is done with it; any cached goal was dropped by the forward above)
         rc = launch_facet(h->prec, h->qkv, h->x, n_frames, T, h->cfg.heads, facet,
-                          (facet == 0 && h->prec != PREC_F32) ? 1.0f / kAttnQScale : 1.0f, 1, st);   // the q rows carry the attention scale
+                          (facet == 0 && plain16(h->prec)) ? 1.0f / kAttnQScale : 1.0f, 1, st);   // the q rows carry the attention scale
         if (rc) return set_err(h, rc, "facet launch failed");
     }
     if (bin) {
@@ -838,7 +932,8 @@ int vitvs_extract_saliency_dev(vitvs_handle* h, int32_t n_frames, const uint8_t*
     hipStream_t st = as_stream(stream);
     int rc = forward(h, n_frames, frames, 0, nullptr, st);   // the last block's qkv launch leaves its output in h->qkv
     if (rc) return rc;
-    rc = launch_saliency(h->prec, h->qkv, saliency, n_frames, h->T, h->cfg.heads, head_idxs, n_heads, h->prec != PREC_F32, st);
+    if (h->prec == PREC_X2) return set_err(h, -5, "saliency maps are not available in the f16x2 precision (use fp32)");
+    rc = launch_saliency(h->prec, h->qkv, saliency, n_frames, h->T, h->cfg.heads, head_idxs, n_heads, plain16(h->prec), st);
     if (rc) return set_err(h, rc, rc == -3 ? "too many tokens for the saliency kernel's LDS rows" : "saliency launch failed");
     return 0;
 }
@@ -871,6 +966,7 @@ int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t* nn_1, con
     if ((size_t)T > h->best_elems) return set_err(h, -3, "T exceeds the handle's workspace");
     DeviceScope dev(h);
     hipStream_t st = as_stream(stream);
+    h->details_pinned = false;
     int rc = launch_encode_best(nn_1, nn_2, sim_1, T, h->row_best, h->col_best, st);
     if (rc) return set_err(h, rc, "encode launch failed");
     VITVS_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->st_nsel), n_selected, 1, st));
@@ -887,7 +983,13 @@ struct UpdateArgs {
     const int32_t *selection, *n_selected;
     double* v_c;
     int32_t* status;
+    // host-pointer entry point: the caller's depth image is copied into the pinned staging block on the HOST, after the
+    // forward's launches have been enqueued and before the law's launch (the only kernel that reads it): off the critical path
+    const void* late_src = nullptr;
+    void* late_dst = nullptr;
+    size_t late_bytes = 0;
 };
+static inline void late_inputs(const UpdateArgs& u) { if (u.late_src) memcpy(u.late_dst, u.late_src, u.late_bytes); }
 
 static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
@@ -906,6 +1008,7 @@ static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) 
         { Span sp(h, KC_GRAM_STENCIL, st);
           rc = launch_gram_stencil_argmax(h->gram_ws, h->sq, h->T, h->grid, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
         if (rc) return set_err(h, rc, "gram stencil launch failed");
+        late_inputs(u);
         return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.num_pairs, u.selection, u.n_selected, u.v_c, u.status, st);
     }
     if (!desc_in_forward(h)) {
@@ -922,6 +1025,7 @@ static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) 
       rc = h->dh ? launch_gram_argmax_split(h->dh, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st)
                  : launch_gram_argmax(h->dn, h->T, h->Dp, u.n_pairs, u.des_shared ? 1 : 0, h->row_best, h->col_best, st); }
     if (rc) return set_err(h, rc, "gram launch failed");
+    late_inputs(u);
     return run_servo(h, u.n_pairs, h->T, u.Z_mm, u.K, u.select_mode, u.num_pairs, u.selection, u.n_selected, u.v_c,
                      u.status, st);
 }
@@ -933,9 +1037,10 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
     const size_t sel_elems = u.select_mode == VITVS_SELECT_EXPLICIT ? (size_t)u.n_pairs * u.num_pairs
                              : (u.select_mode == VITVS_SELECT_ORDER ? (size_t)u.n_pairs * h->T : 0);
     if (sel_elems && u.selection && u.selection != h->st_sel)
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, u.selection, sel_elems * 4, hipMemcpyDeviceToDevice, st));
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, u.selection, sel_elems * 4, hipMemcpyDefault, st));
     if (u.select_mode == VITVS_SELECT_EXPLICIT && u.n_selected && u.n_selected != h->st_nsel)
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, u.n_selected, (size_t)u.n_pairs * 4, hipMemcpyDeviceToDevice, st));
+        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, u.n_selected, (size_t)u.n_pairs * 4, hipMemcpyDefault, st));
+    late_inputs(u);                             // a replay has no seam to do this later: before the launch
     if (u.selection) u.selection = h->st_sel;
     if (u.n_selected) u.n_selected = h->st_nsel;
     const std::vector<uintptr_t> key = {(uintptr_t)u.n_pairs, (uintptr_t)u.I_cur, (uintptr_t)u.I_des, (uintptr_t)u.des_shared,
@@ -957,7 +1062,9 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
         vitvs_handle::GraphEntry fresh;
         fresh.key = key;
         VITVS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_update(h, u, st);
+        UpdateArgs cap = u;
+        cap.late_src = nullptr;                 // (done above)
+        const int rc = enqueue_update(h, cap, st);
         hipError_t e = hipStreamEndCapture(st, &fresh.graph);
         if (rc) {
             if (fresh.graph) (void)hipGraphDestroy(fresh.graph);
@@ -996,37 +1103,50 @@ int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des) {
     if (!h || !I_des) return set_err(h, -1, "null argument");
     if (n_goal <= 0 || n_goal > h->cfg.max_pairs) return set_err(h, -3, "n_goal exceeds max_pairs");
     DeviceScope dev(h);
+    if (int rc = ensure_host_stage(h)) return rc;
     const size_t img = frame_bytes(h);
-    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, n_goal * img, hipMemcpyHostToDevice, nullptr));
-    const int rc = vitvs_set_goal_dev(h, n_goal, h->st_des, nullptr);
+    memcpy(h->hs.des, I_des, n_goal * img);
+    int rc = launch_copy16(h->hs.des, h->st_des, n_goal * img, h->host_stream);
+    if (rc) return set_err(h, rc, "frame staging launch failed");
+    rc = vitvs_set_goal_dev(h, n_goal, h->st_des, h->host_stream);
     if (rc) return rc;
-    VITVS_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return 0;
+    return wait_stream(h->host_stream);
+}
+
+// Validation + dispatch shared by the device-pointer and the host-pointer entry points (`u` carries the latter's late input).
+static int velocity_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
+    if (!u.I_cur || !u.K || !u.v_c || !u.status) return set_err(h, -1, "null argument");   // I_des NULL: the cached goal
+    if (u.n_pairs <= 0 || u.n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
+    u.num_pairs = call_num_pairs(h, u.num_pairs);
+    if (u.num_pairs > h->cfg.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
+    if (u.select_mode != VITVS_SELECT_DENSE && !u.selection) return set_err(h, -5, "selection array required for this mode");
+    if (u.select_mode == VITVS_SELECT_EXPLICIT && !u.n_selected) return set_err(h, -5, "n_selected required for EXPLICIT");
+    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
+    // The goal cache is host-side state of the handle: it is checked and invalidated here, on every call, and never
+    // inside the body that a hipGraph captures (a replay runs none of the body's host code).
+    if (!u.I_des && h->goal_frames != (u.des_shared ? 1 : u.n_pairs))
+        return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
+    if (u.I_des) h->goal_frames = 0;            // the call forwards goal frames of its own over the cached rows
+    h->details_pinned = false;                  // the detail block on the device is about to change
+    if (h->use_graphs && !h->timing && st != nullptr) return replay_update(h, u, st);
+    return enqueue_update(h, u, st);
 }
 
 int vitvs_compute_velocity_dev(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                                int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                                const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
                                int32_t* status, void* stream) {
-    if (!h || !I_cur || !K || !v_c || !status) return set_err(h, -1, "null argument");   // I_des NULL: the cached goal
-    if (n_pairs <= 0 || n_pairs > h->cfg.max_pairs) return set_err(h, -3, "n_pairs exceeds max_pairs");
-    const int np = call_num_pairs(h, num_pairs);
-    if (np > h->cfg.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
-    if (select_mode != VITVS_SELECT_DENSE && !selection) return set_err(h, -5, "selection array required for this mode");
-    if (select_mode == VITVS_SELECT_EXPLICIT && !n_selected) return set_err(h, -5, "n_selected required for EXPLICIT");
+    if (!h) return set_err(h, -1, "null argument");
     DeviceScope dev(h);
-    if (vitvs_weights_ready(h) != 0) return set_err(h, -4, "weights not fully loaded: " + h->err);
-    hipStream_t st = as_stream(stream);
-    const UpdateArgs u{n_pairs, des_shared, select_mode, np, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
-    // The goal cache is host-side state of the handle: it is checked and invalidated here, on every call, and never
-    // inside the body that a hipGraph captures (a replay runs none of the body's host code).
-    if (!I_des && h->goal_frames != (des_shared ? 1 : n_pairs))
-        return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
-    if (I_des) h->goal_frames = 0;              // the call forwards goal frames of its own over the cached rows
-    if (h->use_graphs && !h->timing && st != nullptr) return replay_update(h, u, st);
-    return enqueue_update(h, u, st);
+    UpdateArgs u{n_pairs, des_shared, select_mode, num_pairs, I_cur, I_des, Z_mm, K, selection, n_selected, v_c, status};
+    return velocity_update(h, u, as_stream(stream));
 }
 
+// The reference's seam as it is called (vitvs_v2.py:464-523, 588-632: numpy arrays in, a numpy twist out).  Per call: the
+// frames, intrinsics and selection are copied into the handle's pinned block by memcpy; the frames go on to device memory
+// in one short launch on the update's stream; the forward is enqueued; THEN the depth image is copied (host) — the law's
+// kernel is the only reader, it is enqueued last and reads the <= max_rows pixels it needs in place; v_c, status and the
+// feature rows come back through the pinned block; one polled wait.
 int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cur, const uint8_t* I_des,
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                            const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
@@ -1036,28 +1156,38 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     const vitvs_config& c = h->cfg;
     const int np = call_num_pairs(h, num_pairs);
     if (np > c.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
+    if (select_mode == VITVS_SELECT_EXPLICIT && (!selection || !n_selected)) return set_err(h, -5, "EXPLICIT selection needs ids and counts");
+    if (select_mode == VITVS_SELECT_ORDER && !selection) return set_err(h, -5, "ORDER selection needs a visiting order");
     DeviceScope dev(h);
-    const size_t img = frame_bytes(h);
-    hipStream_t st = nullptr;
-    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_cur, I_cur, n_pairs * img, hipMemcpyHostToDevice, st));
-    if (I_des) VITVS_HIP_CHECK(hipMemcpyAsync(h->st_des, I_des, (des_shared ? 1 : n_pairs) * img, hipMemcpyHostToDevice, st));
-    if (Z_mm)
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_depth, Z_mm, (size_t)n_pairs * c.u_max * c.v_max * 2, hipMemcpyHostToDevice, st));
-    VITVS_HIP_CHECK(hipMemcpyAsync(h->st_K, K, (size_t)n_pairs * 4 * sizeof(double), hipMemcpyHostToDevice, st));
-    if (select_mode == VITVS_SELECT_EXPLICIT) {
-        if (!selection || !n_selected) return set_err(h, -5, "EXPLICIT selection needs ids and counts");
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * np * 4, hipMemcpyHostToDevice, st));
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_nsel, n_selected, (size_t)n_pairs * 4, hipMemcpyHostToDevice, st));
-    } else if (select_mode == VITVS_SELECT_ORDER) {
-        if (!selection) return set_err(h, -5, "ORDER selection needs a visiting order");
-        VITVS_HIP_CHECK(hipMemcpyAsync(h->st_sel, selection, (size_t)n_pairs * h->T * 4, hipMemcpyHostToDevice, st));
+    if (int rc = ensure_host_stage(h)) return rc;
+    vitvs_handle::HostStage& hs = h->hs;
+    hipStream_t st = h->host_stream;
+    const size_t img = frame_bytes(h), n_des = des_shared ? 1 : n_pairs;
+    memcpy(hs.cur, I_cur, n_pairs * img);
+    int rc = launch_copy16(hs.cur, h->st_cur, n_pairs * img, st);
+    if (!rc && I_des) {
+        memcpy(hs.des, I_des, n_des * img);
+        rc = launch_copy16(hs.des, h->st_des, n_des * img, st);
     }
-    int rc = vitvs_compute_velocity_dev(h, n_pairs, h->st_cur, I_des ? h->st_des : nullptr, des_shared, Z_mm ? h->st_depth : nullptr,
-                                        h->st_K, select_mode, h->st_sel, h->st_nsel, np, h->st_vc, h->st_status, st);
+    if (rc) return set_err(h, rc, "frame staging launch failed");
+    memcpy(hs.K, K, (size_t)n_pairs * 4 * sizeof(double));
+    if (select_mode == VITVS_SELECT_EXPLICIT) {
+        memcpy(hs.sel, selection, (size_t)n_pairs * np * 4);
+        memcpy(hs.nsel, n_selected, (size_t)n_pairs * 4);
+    } else if (select_mode == VITVS_SELECT_ORDER) {
+        memcpy(hs.sel, selection, (size_t)n_pairs * h->T * 4);
+    }
+    UpdateArgs u{n_pairs, des_shared, select_mode, np, h->st_cur, I_des ? h->st_des : nullptr, Z_mm ? hs.depth : nullptr, hs.K,
+                 hs.sel, hs.nsel, hs.vc, hs.status};
+    if (Z_mm) { u.late_src = Z_mm; u.late_dst = hs.depth; u.late_bytes = (size_t)n_pairs * c.u_max * c.v_max * 2; }
+    rc = velocity_update(h, u, st);
     if (rc) return rc;
-    VITVS_HIP_CHECK(hipMemcpyAsync(v_c, h->st_vc, (size_t)n_pairs * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    VITVS_HIP_CHECK(hipMemcpyAsync(status, h->st_status, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
-    VITVS_HIP_CHECK(hipStreamSynchronize(st));
+    rc = launch_copy16(h->det_block, hs.det, h->det_bytes, st);      // info | s_uv | feat of this call: vitvs_last_details
+    if (rc) return set_err(h, rc, "detail copy launch failed");
+    if (int w = wait_stream(st)) return w;
+    memcpy(v_c, hs.vc, (size_t)n_pairs * 6 * sizeof(double));
+    memcpy(status, hs.status, (size_t)n_pairs * 4);
+    h->details_pinned = true;
     return 0;
 }
 
@@ -1066,17 +1196,28 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
     if (!h) return set_err(h, -1, "null argument");
     if (n_pairs <= 0 || n_pairs > h->last_pairs) return set_err(h, -3, "no such pairs in the last call");
     DeviceScope dev(h);
-    VITVS_HIP_CHECK(hipDeviceSynchronize());
-    const size_t T = h->last_T, R = h->cfg.max_rows, P = n_pairs;
+    const size_t T = h->last_T, R = h->cfg.max_rows, P = n_pairs, PM = h->cfg.max_pairs;
+    // after a host-pointer call the feature rows are already in host memory (the handle's pinned block): a caller that asks
+    // for those alone (the reference's detect_features return value: s_uv*, s_uv, the selected similarities) costs no HIP call
+    const bool pinned = h->details_pinned;
+    const unsigned char* pd = h->hs.det;
+    if (!pinned || nn_1 || nn_2 || sim_1 || selected || L) VITVS_HIP_CHECK(hipDeviceSynchronize());
     if (nn_1) VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
     if (nn_2) VITVS_HIP_CHECK(hipMemcpy(nn_2, h->nn2, P * T * 4, hipMemcpyDeviceToHost));
     if (sim_1) VITVS_HIP_CHECK(hipMemcpy(sim_1, h->sim1, P * T * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> inf(P * 8);
-    VITVS_HIP_CHECK(hipMemcpy(inf.data(), h->info, P * 8 * 4, hipMemcpyDeviceToHost));
+    if (pinned) memcpy(inf.data(), pd, P * 8 * 4);
+    else VITVS_HIP_CHECK(hipMemcpy(inf.data(), h->info, P * 8 * 4, hipMemcpyDeviceToHost));
     if (info) memcpy(info, inf.data(), P * 8 * 4);
     if (selected) VITVS_HIP_CHECK(hipMemcpy(selected, h->sel_out, P * R * 4, hipMemcpyDeviceToHost));
-    if (s_uv) VITVS_HIP_CHECK(hipMemcpy(s_uv, h->s_uv, P * R * 4 * 4, hipMemcpyDeviceToHost));
-    if (feat) VITVS_HIP_CHECK(hipMemcpy(feat, h->feat, P * R * 4 * 8, hipMemcpyDeviceToHost));
+    if (s_uv) {
+        if (pinned) memcpy(s_uv, pd + PM * 32, P * R * 16);
+        else VITVS_HIP_CHECK(hipMemcpy(s_uv, h->s_uv, P * R * 4 * 4, hipMemcpyDeviceToHost));
+    }
+    if (feat) {
+        if (pinned) memcpy(feat, pd + PM * 32 + PM * R * 16, P * R * 32);
+        else VITVS_HIP_CHECK(hipMemcpy(feat, h->feat, P * R * 4 * 8, hipMemcpyDeviceToHost));
+    }
     if (L) VITVS_HIP_CHECK(hipMemcpy(L, h->Lws, P * 7 * 2 * R * 8, hipMemcpyDeviceToHost));
     // The kernel writes the first n_feature_rows (info[1]) rows of a pair; the workspace rows behind them may still hold
     // an earlier, larger call's values.  The copies handed out are defined everywhere: selected = -1, everything else 0.
@@ -1148,7 +1289,12 @@ int vitvs_timing_collect(vitvs_handle* h, int32_t n_classes, double* total_ms, i
 int vitvs_op_linear(int32_t precision, const void* A, const void* W, const float* bias, void* out, int32_t M,
                     int32_t N, int32_t K, int32_t gelu, void* stream) {
     DeviceScope dev(nullptr);
-    return launch_linear(to_prec(precision), A, W, bias, out, M, N, K, gelu, as_stream(stream));
+    return launch_linear(to_prec(precision), A, W, bias, out, M, N, K, gelu, as_stream(stream), g_op_wexp);
+}
+int vitvs_op_weight_exponent(int32_t e) {
+    const int prev = g_op_wexp;
+    if (e >= 0 && e <= 31) g_op_wexp = e;
+    return prev;
 }
 int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, const void* W, const float* bias, void* out,
                             int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t slices, void* stream) {
@@ -1156,11 +1302,12 @@ int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, c
     const Precision p = to_prec(precision);
     hipStream_t st = as_stream(stream);
     if (variant == 0)
-        return slices > 0 ? launch_linear_partial(p, A, W, (float*)out, M, N, K, slices, st)
-                          : launch_linear(p, A, W, bias, out, M, N, K, gelu, st);
+        return slices > 0 ? launch_linear_partial(p, A, W, (float*)out, M, N, K, slices, st, g_op_wexp)
+                          : launch_linear(p, A, W, bias, out, M, N, K, gelu, st, g_op_wexp);
     if (variant == 1)
-        return slices > 0 ? launch_linear_partial_classic(p, A, W, (float*)out, M, N, K, slices, st)
-                          : launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, st);
+        return slices > 0 ? launch_linear_partial_classic(p, A, W, (float*)out, M, N, K, slices, st, g_op_wexp)
+                          : launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, st, g_op_wexp);
+    if (p == PREC_X2) return -2;                   // the tile families below are 16-bit only
     if (variant == 2) return launch_linear_128(p, A, W, bias, out, M, N, K, gelu, slices > 0 ? slices : 1, slices > 0, st);
     if (variant == 1256) return (N % 256 || K % 64) ? -2 : launch_linear_big(p, 1256, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
     if (variant == 1192) return (N % 128 || K % 64) ? -2 : launch_linear_big(p, 1192, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
@@ -1170,7 +1317,7 @@ int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, c
 int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
                              float* x, int32_t M, int32_t N, int32_t K, void* stream) {
     DeviceScope dev(nullptr);
-    return launch_linear_residual(to_prec(precision), A, W, bias, ls, x, M, N, K, as_stream(stream));
+    return launch_linear_residual(to_prec(precision), A, W, bias, ls, x, M, N, K, as_stream(stream), g_op_wexp);
 }
 int vitvs_op_layernorm(int32_t precision, const float* x, const float* gamma, const float* beta, void* out, int32_t M,
                        int32_t D, float eps, void* stream) {
@@ -1186,7 +1333,7 @@ int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out, int32_t 
                          int32_t q_prescaled, void* stream) {
     DeviceScope dev(nullptr);
     const Precision p = to_prec(precision);
-    return launch_attention(p, qkv, out, n_img, N, H, as_stream(stream), nullptr, q_prescaled != 0 && p != PREC_F32);
+    return launch_attention(p, qkv, out, n_img, N, H, as_stream(stream), nullptr, q_prescaled != 0 && plain16(p));
 }
 int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int32_t slices, int32_t* tile) {
     if (!tile) return -1;
@@ -1206,7 +1353,7 @@ int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K) {
 int vitvs_op_linear_partial(int32_t precision, const void* A, const void* W, float* part, int32_t M, int32_t N,
                             int32_t K, int32_t slices, void* stream) {
     DeviceScope dev(nullptr);
-    return launch_linear_partial(to_prec(precision), A, W, part, M, N, K, slices, as_stream(stream));
+    return launch_linear_partial(to_prec(precision), A, W, part, M, N, K, slices, as_stream(stream), g_op_wexp);
 }
 int vitvs_op_residual_ln(int32_t precision, float* x, const float* part, int32_t slices, const float* bias,
                          const float* ls, const float* gamma, const float* beta, void* out, int32_t M, int32_t D,

@@ -918,6 +918,358 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------ split-f16 (f16x2)
+// The fp32-class mode on the f16 matrix cores (common.h hx2): q, k, v arrive as hi / lo pairs — a head's 64 dims are 256
+// bytes, [hi 0-31 | lo 0-31 | hi 32-63 | lo 32-63] — and both contractions run as hi.hi + hi.lo + lo.hi (three
+// v_mfma_f32_16x16x32_f16 per k-step, fp32 accumulate; the dropped lo.lo term is < 2^-22 of the product).  Same orientation
+// and online softmax as attention_16_kernel (S^T = K Q^T, P in registers as the B operand of O^T += V^T P^T), fp32
+// statistics; q is NOT pre-scaled (the scores leave the matrix pipe raw and take hd^-0.5 log2 e in fp32, like
+// attention_f32_kernel).  P is split in registers: p' = exp2(s - m + 8) puts the probabilities at 2^8 so that the lo halves
+// of all but negligible weights are normal fp16 numbers; the factor cancels in O / l.
+// LDS per key group: K tile [64 keys][256 B] with the chunk swizzle of tile256_off, V tile [64][256 B] with its 32-byte
+// windows XOR-swizzled by (key & 7), so the four key rows a hardware-transposed read touches lie in four windows.
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void attention_x2_kernel(const hx2* __restrict__ qkv, hx2* __restrict__ out, int N, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = tid >> 6, kgp = wave_all >> 2, wave = wave_all & 3, tl = tid & 255;
+    unsigned char* ldsK = smem + kgp * (2 * 64 * 256);
+    unsigned char* ldsV = ldsK + 64 * 256;
+    const int qi = lane & 15, g = lane >> 4;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int img = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const size_t ldb = (size_t)12 * D;                         // bytes per token row: 3 D logical columns x (hi + lo)
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(qkv) + (size_t)img * N * ldb + h * 256;
+    const unsigned char* Kp = base + 4 * (size_t)D;
+    const unsigned char* Vp = base + 8 * (size_t)D;
+
+    const int q = q0 + 16 * wave + qi;
+    const int qrow = min(q, N - 1);
+    f16x8 qh[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qh[s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ldb + (8 * s + g) * 16));
+        ql[s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (size_t)qrow * ldb + (8 * s + 4 + g) * 16));
+    }
+    // this lane's corner of a transposed V read: key row 4g + (qi >> 2) of a 16-key group, 8 bytes at 8 (qi & 3) inside a
+    // 32-byte window; window w of that row sits at slot w ^ rsw (rsw = the row's low three bits, the same for every group)
+    const int rsw = 4 * (g & 1) + (qi >> 2);
+    lds_u8* vtr = (lds_u8*)ldsV + (4 * g + (qi >> 2)) * 256 + 8 * (qi & 3);
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int srow = tl >> 4, schunk = tl & 15;
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = min(kb + srow + 16 * i, N - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)key * ldb + schunk * 16);
+            rv[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)key * ldb + schunk * 16);
+        }
+    };
+    const int ntiles = (N + 63) / 64;
+    const int per_group = (ntiles + KS - 1) / KS;
+    const int first = kgp * per_group;
+    gload(min(first, ntiles - 1) * 64);
+    for (int tt = 0; tt < per_group; ++tt) {
+        const int t = first + tt;
+        const int kb = t * 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 16 * i;
+            *reinterpret_cast<u32x4*>(ldsK + tile256_off(r, schunk)) = rk[i];
+            *reinterpret_cast<u32x4*>(ldsV + r * 256 + ((((schunk >> 1) ^ (r & 7)) << 5) | ((schunk & 1) << 4))) = rv[i];
+        }
+        __syncthreads();
+        if (tt + 1 < per_group) gload(min(t + 1, ntiles - 1) * 64);
+        if (t >= ntiles) continue;   // wave-uniform: this key group has run out of tiles (barriers above still taken)
+
+        // S^T tiles: acc_s[t4][r] = S[key = kb + 16*t4 + 4g + r][q]
+        f32x4 acc_s[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 kh[4], kl[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                kh[t4] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsK + tile256_off(16 * t4 + qi, 8 * s + g)));
+                kl[t4] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsK + tile256_off(16 * t4 + qi, 8 * s + 4 + g)));
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kl[t4], qh[s], acc_s[t4]);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4], ql[s], acc_s[t4]);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4], qh[s], acc_s[t4]);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + 16 * t4 + 4 * g + r;
+                float x = acc_s[t4][r] * kScaleLog2e;
+                x = (key < N) ? x : -INFINITY;
+                acc_s[t4][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        mloc = rows_max(mloc);
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        const float shift = 8.0f - m_new;                     // p' = 2^8 p (header)
+        float psum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(acc_s[t4][r] + shift);
+                acc_s[t4][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+
+        // O^T += V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = acc_s[2 * u + (j >> 2)][j & 3];
+                const f16 hi = (f16)p;
+                ph[j] = hi;
+                pl[j] = (f16)(p - (float)hi);
+            }
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                // head dims 16 td .. 16 td + 15: hi halves in window 4 (td >> 1) + (td & 1) of a key row, lo halves two windows on
+                const int wh = 4 * (td >> 1) + (td & 1);
+                lds_u8* ph0 = vtr + (32 * u) * 256 + ((wh ^ rsw) << 5);
+                lds_u8* pl0 = vtr + (32 * u) * 256 + (((wh + 2) ^ rsw) << 5);
+                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ph0);
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ph0 + 16 * 256));
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pl0);
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl0 + 16 * 256));
+                const f16x8 vh = __builtin_bit_cast(f16x8, (s16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+                const f16x8 vl = __builtin_bit_cast(f16x8, (s16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+                acc_o[td] = mfma16(vl, ph, acc_o[td]);
+                acc_o[td] = mfma16(vh, pl, acc_o[td]);
+                acc_o[td] = mfma16(vh, ph, acc_o[td]);
+            }
+        }
+    }
+    if constexpr (KS >= 2) {
+        // merge the key groups' online-softmax states: groups 1 .. KS-1 -> LDS -> group 0 (fixed order)
+        __syncthreads();
+        f32x4* buf = reinterpret_cast<f32x4*>(smem) + (wave * 64 + lane);   // [KS-1][5][256] x 16 B
+        if (kgp >= 1) {
+            f32x4* mine = buf + (kgp - 1) * 5 * 256;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) mine[td * 256] = acc_o[td];
+            mine[4 * 256] = f32x4{m_run, l_run, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (kgp >= 1) return;
+#pragma unroll
+        for (int o = 0; o < KS - 1; ++o) {
+            const f32x4* other = buf + o * 5 * 256;
+            const f32x4 ml = other[4 * 256];
+            const float m_tot = fmaxf(m_run, ml[0]);
+            const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(ml[0] - m_tot);
+            m_run = m_tot;
+            l_run = l_run * wa + ml[1] * wb;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const f32x4 ob = other[td * 256];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_o[td][r] = acc_o[td][r] * wa + ob[r] * wb;
+            }
+        }
+    }
+    l_run = rows_sum(l_run);
+    const float inv = 1.0f / l_run;
+    if (q < N) {
+        hx2* dst = out + ((size_t)img * N + q) * D * 2;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            const f32x4 o = {acc_o[td][0] * inv, acc_o[td][1] * inv, acc_o[td][2] * inv, acc_o[td][3] * inv};
+            if constexpr (KS >= 2) store_x2<true>(dst, h * 64 + 16 * td + 4 * g, o);   // key-split variants only run on small grids
+            else store_x2<false>(dst, h * 64 + 16 * td + 4 * g, o);
+        }
+    }
+}
+
+// f16x2, short sequences (N <= 256: the 197 tokens of a 224² frame) — attention_16_short_kernel's arrangement for hi / lo
+// operands: one workgroup = 16 queries of one (image, head), wave w = key tile w; every wave requests its whole input at
+// entry in one round trip (Q and its 64 keys, both halves, straight into MFMA operand registers; its 64 values into a
+// wave-private 16 KB slab by LDS-DMA, the window swizzle of attention_x2_kernel applied on the SOURCE side) and runs one
+// score -> softmax -> PV chain; the four states are merged in parallel through the slabs themselves (a wave parks its state in
+// its own slab once its PV reads are done: 64 KB of LDS per workgroup, two workgroups per CU), wave w finishing head dims
+// 16 w .. 16 w + 15.  Same 1-D XCD-aware item order as the 16-bit kernel.
+__global__ __launch_bounds__(256) void attention_x2_short_kernel(const hx2* __restrict__ qkv, hx2* __restrict__ out, int N, int D,
+                                                                 int n_img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 15, g = lane >> 4;
+    const int H = D >> 6, nqb = (N + 15) >> 4, items = n_img * H * nqb, per = (items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= items) return;
+    const int pair = item / nqb;
+    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 16;
+    const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
+    const unsigned row_bytes = 12u * (unsigned)D;                                  // 3 D logical columns x (hi + lo)
+    const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 256u;
+    const unsigned k_off = head_off + 4u * (unsigned)D, v_off = head_off + 8u * (unsigned)D;
+    unsigned char* ldsV = smem + wave * 16384;                                     // [64 keys][256 B], this wave's tile
+    const int rsw = 4 * (g & 1) + (qi >> 2);
+    lds_u8* vtr = (lds_u8*)ldsV + (4 * g + (qi >> 2)) * 256 + 8 * (qi & 3);
+    const int kb = wave * 64;
+    const bool active = kb < N;                                                    // wave-uniform
+    const int q = q0 + qi;
+    f16x8 qh[2], ql[2], kh[4][2], kl[4][2];
+    {
+        const unsigned o = head_off + __umul24((unsigned)min(q, N - 1), row_bytes) + 16u * (unsigned)g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qh[s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qb + (o + 128u * s)));
+            ql[s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qb + (o + 128u * s + 64u)));
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const unsigned o = k_off + __umul24((unsigned)min(kb + 16 * t4 + qi, N - 1), row_bytes) + 16u * (unsigned)g;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kh[t4][s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qb + (o + 128u * s)));
+                kl[t4][s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qb + (o + 128u * s + 64u)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            // copy j fills key rows 4 j .. 4 j + 3 of the slab linearly; lane l lands in slot (l & 15) of row 4 j + (l >> 4),
+            // which must hold the chunk whose window is that slot's window XOR the row's low bits
+            const int r = 4 * j + (lane >> 4), sl = lane & 15;
+            const int c = ((((sl >> 1) ^ (r & 7)) << 1) | (sl & 1));
+            const unsigned o = v_off + __umul24((unsigned)min(kb + r, N - 1), row_bytes) + 16u * (unsigned)c;
+            __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + o), (lds_ptr)(ldsV + j * 1024), 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every request is issued before anything waits on one
+
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int td = 0; td < 4; ++td) acc_o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    if (active) {
+        f32x4 acc_s[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kl[t4][s], qh[s], acc_s[t4]);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4][s], ql[s], acc_s[t4]);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4][s], qh[s], acc_s[t4]);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + 16 * t4 + 4 * g + r;
+                float x = acc_s[t4][r] * kScaleLog2e;
+                x = (key < N) ? x : -INFINITY;
+                acc_s[t4][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        m_run = rows_max(mloc);               // the tile's first key is valid (kb < N), so this is finite
+        const float shift = 8.0f - m_run;     // p' = 2^8 p: the lo halves of all but negligible weights are normal fp16 numbers
+        float psum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(acc_s[t4][r] + shift);
+                acc_s[t4][r] = p;
+                psum += p;
+            }
+        l_run = rows_sum(psum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's V slab has landed (its own LDS-DMA copies)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = acc_s[2 * u + (j >> 2)][j & 3];
+                const f16 hi = (f16)p;
+                ph[j] = hi;
+                pl[j] = (f16)(p - (float)hi);
+            }
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const int wh = 4 * (td >> 1) + (td & 1);
+                lds_u8* ph0 = vtr + (32 * u) * 256 + ((wh ^ rsw) << 5);
+                lds_u8* pl0 = vtr + (32 * u) * 256 + (((wh + 2) ^ rsw) << 5);
+                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ph0);
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ph0 + 16 * 256));
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pl0);
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl0 + 16 * 256));
+                const f16x8 vh = __builtin_bit_cast(f16x8, (s16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+                const f16x8 vl = __builtin_bit_cast(f16x8, (s16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+                acc_o[td] = mfma16(vl, ph, acc_o[td]);
+                acc_o[td] = mfma16(vh, pl, acc_o[td]);
+                acc_o[td] = mfma16(vh, ph, acc_o[td]);
+            }
+        }
+    }
+    // parallel merge through the slabs: wave w parks its state in its OWN slab (its PV reads are complete: the accumulators
+    // that depend on them are its operands here), wave w finishes head dims 16 w .. 16 w + 15
+    f32x4* mine = reinterpret_cast<f32x4*>(ldsV) + lane;
+#pragma unroll
+    for (int td = 0; td < 4; ++td) mine[td * 64] = acc_o[td];
+    mine[4 * 64] = f32x4{m_run, l_run, 0.f, 0.f};
+    __syncthreads();
+    float m_k[4], l_k[4];
+    float m_tot = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 ml = reinterpret_cast<const f32x4*>(smem + k * 16384)[4 * 64 + lane];
+        m_k[k] = ml[0];
+        l_k[k] = ml[1];
+        m_tot = fmaxf(m_tot, m_k[k]);
+    }
+    float l_tot = 0.f;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = fast_exp2(m_k[k] - m_tot);          // 0 for a wave without keys (m = -inf)
+        l_tot += l_k[k] * wk;
+        const f32x4 ok = reinterpret_cast<const f32x4*>(smem + k * 16384)[wave * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += ok[r] * wk;
+    }
+    const float inv = 1.0f / l_tot;
+    if (q < N) store_x2<true>(out + ((size_t)img * N + q) * D * 2, h * 64 + 16 * wave + 4 * g, f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv});
+}
+
 #ifdef VITVS_PROBE
 extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe(void* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
@@ -1053,7 +1405,15 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
     const int nt = (N + 63) / 64;
     dim3 grid(nt, H, n_img);
     int rc = 0;
-    if (p == PREC_F32) {
+    if (p == PREC_X2) {
+        const int items16 = ((N + 15) / 16) * H * n_img;
+        if (N <= 256 && items16 <= 640 && (long)n_img * N * 12 * D < (1l << 32))
+            launch(attention_x2_short_kernel, dim3(8 * ((items16 + 7) / 8)), dim3(256), 4 * 16384, stream, (const hx2*)qkv, (hx2*)out, N, D, n_img);
+        else if ((long)nt * H * n_img <= 256 && nt >= 2)
+            launch((attention_x2_kernel<2>), grid, dim3(512), 2 * 2 * 64 * 256, stream, (const hx2*)qkv, (hx2*)out, N, D);
+        else
+            launch((attention_x2_kernel<1>), grid, dim3(256), 2 * 64 * 256, stream, (const hx2*)qkv, (hx2*)out, N, D);
+    } else if (p == PREC_F32) {
         launch(attention_f32_kernel, grid, dim3(256), 0, stream, (const float*)qkv, (float*)out, N, D);
     } else if (p == PREC_F16) {
         rc = launch_attention_16<f16>((const f16*)qkv, (f16*)out, n_img, N, H, stream, ws, q_prescaled);

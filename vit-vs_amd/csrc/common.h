@@ -20,10 +20,24 @@ constexpr int WAVE = 64;
 
 
 
+// Split-f16 ("f16x2") storage: a value v is kept as TWO fp16 numbers, hi = fp16(v) and lo = fp16(v - hi) (22 significant
+// bits), and a contraction runs as hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation — the dropped
+// lo.lo term is below 2^-22 of the product, i.e. fp32-class results at three 16-bit MFMAs per k-step instead of the
+// sixteen-times-slower fp32 matrix pipe (reference arithmetic: fp32 throughout, dinov2_extractor.py:245-263).
+// Layout of a row of C logical columns (C % 32 == 0): 2 C fp16, in groups of 64 = [hi of 32 columns | lo of the same 32
+// columns]; a 128-byte k-tile of the GEMM ring is then 32 k with both halves, and MFMA step 0 / 1 of the tile loop
+// (gemm_core.h) reads the hi / lo fragments.  hx2 is the storage unit (one fp16); sizeof == 2 like the 16-bit types.
+struct hx2 { unsigned short bits; };
+template <typename T> inline constexpr bool kSplit = false;
+template <> inline constexpr bool kSplit<hx2> = true;
+// f16 index of logical column c inside an f16x2 row (hi half; the lo half is 32 further on)
+__device__ __host__ __forceinline__ int x2_index(int c) { return ((c >> 5) << 6) | (c & 31); }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; };
 template <> struct Elem<bf16> { static constexpr int PER_CHUNK = 8; };
 template <> struct Elem<f16> { static constexpr int PER_CHUNK = 8; };
+template <> struct Elem<hx2> { static constexpr int PER_CHUNK = 8; };
 // the two 16-bit operand types share every kernel: vectors of 4 / 8 elements and the f32-accumulating 16x16x32 MFMA
 template <typename H> struct Vec16;
 template <> struct Vec16<bf16> { typedef bf16x4 x4; typedef bf16x8 x8; };
@@ -57,6 +71,39 @@ template <bool WT>
 __device__ __forceinline__ void store_out(bf16* p, bf16x4 v) { store_out8<WT>(p, __builtin_bit_cast(unsigned long long, v)); }
 template <bool WT>
 __device__ __forceinline__ void store_out(f16* p, f16x4 v) { store_out8<WT>(p, __builtin_bit_cast(unsigned long long, v)); }
+
+// f16x2: the hi / lo halves of four values.  hi saturates at the fp16 range instead of becoming infinite (lo then carries
+// what is left, so magnitudes up to 2 x 65504 stay finite); below 2^-3 the lo half is an fp16 subnormal — exact to 2^-25
+// absolute, which the matrix cores honour (tools/denorm_probe.py).
+struct Split4 { f16x4 hi, lo; };
+__device__ __forceinline__ Split4 split4(f32x4 v) {
+    Split4 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16 h = (f16)__builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
+        s.hi[i] = h;
+        s.lo[i] = (f16)(v[i] - (float)h);
+    }
+    return s;
+}
+// four consecutive logical columns c .. c + 3 (c % 4 == 0) of an f16x2 row
+template <bool WT>
+__device__ __forceinline__ void store_x2(hx2* row, int c, f32x4 v) {
+    const Split4 s = split4(v);
+    f16* p = reinterpret_cast<f16*>(row) + x2_index(c);
+    store_out<WT>(p, s.hi);
+    store_out<WT>(p + 32, s.lo);
+}
+__device__ __forceinline__ void store_x2_one(hx2* row, int c, float v) {
+    f16* p = reinterpret_cast<f16*>(row) + x2_index(c);
+    const f16 h = (f16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    p[0] = h;
+    p[32] = (f16)(v - (float)h);
+}
+__device__ __forceinline__ float load_x2(const hx2* row, int c) {
+    const f16* p = reinterpret_cast<const f16*>(row) + x2_index(c);
+    return (float)p[0] + (float)p[32];
+}
 
 // Cross-lane reductions on the VALU (DPP row operations, v_readlane and gfx950's v_permlane{16,32}_swap):
 // the HIP __shfl_* intrinsics go through the LDS crossbar (ds_bpermute, ~100+ cycles of latency per step; a

@@ -5,6 +5,8 @@
 //   nn.LayerNorm(eps=1e-6)          dino_patch/block.py:57,75 (norm1 / norm2)
 //   descriptor = blocks[11] output minus cls   dinov2_extractor.py:326-334; 3x3 log-bin :289-308
 //   cosine normalisation x / max(|x|, 1e-8)    vitvs_v2.py:55 (torch CosineSimilarity)
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
     const uint8_t* src = (img < a.n_des) ? a.des + (size_t)img * a.S * a.S * 3
                                          : a.cur + (size_t)(img - a.n_des) * a.S * a.S * 3;
     const int pp = a.patch * a.patch;
-    T* dst = Ape + (size_t)row * a.Kp;
+    T* dst = Ape + (size_t)row * a.Kp * (kSplit<T> ? 2 : 1);   // f16x2 rows: 2 Kp fp16 (common.h)
     // 4 consecutive k per thread (same channel and patch row when patch % 4 == 0): one 8- or 16-byte write-through store
     // instead of four 2- or 4-byte stores; the patch-embedding GEMM reads these rows in the next launch
     if ((a.patch & 3) == 0) {
@@ -41,7 +43,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)s[3 * j], 255.0f), a.mean[c]), a.std[c]);
             }
-            if constexpr (sizeof(T) == 4) {
+            if constexpr (kSplit<T>) {
+                store_x2<true>(dst, k4, f32x4{v[0], v[1], v[2], v[3]});
+            } else if constexpr (sizeof(T) == 4) {
                 store_out<true>(reinterpret_cast<float*>(dst + k4), make_float4(v[0], v[1], v[2], v[3]));
             } else {
                 const typename Vec16<T>::x4 h = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a, T* __rest
             const float u = (float)src[((size_t)yy * a.S + xx) * 3 + c];
             v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), a.mean[c]), a.std[c]);
         }
-        dst[k] = from_float<T>(v);
+        if constexpr (kSplit<T>) store_x2_one(dst, k, v);
+        else dst[k] = from_float<T>(v);
     }
 }
 
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void patchify_resize_kernel(PatchifyArgs a, Re
     }
     __syncthreads();
     const int pp = a.patch * a.patch;
-    T* dst = Ape + (size_t)row * a.Kp;
+    T* dst = Ape + (size_t)row * a.Kp * (kSplit<T> ? 2 : 1);
     for (int k = tid; k < a.Kp; k += 256) {
         float v = 0.f;
         if (k < 3 * pp) {
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(256) void patchify_resize_kernel(PatchifyArgs a, Re
             for (int i = 0; i < ycnt; ++i) ss += (int)col[i * row3] * kk[i];
             v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)resize_clip8(ss), 255.0f), a.mean[c]), a.std[c]);
         }
-        dst[k] = from_float<T>(v);
+        if constexpr (kSplit<T>) store_x2_one(dst, k, v);
+        else dst[k] = from_float<T>(v);
     }
 }
 
@@ -129,7 +135,9 @@ int launch_patchify(Precision p, const PatchifyArgs& a, const ResizeArgs* rs, vo
     if (rs) {
         const size_t lds = (size_t)rs->rows * a.patch * 3;
         if (lds == 0 || lds > 64 * 1024) return -3;
-        if (p == PREC_F32)
+        if (p == PREC_X2)
+            launch(patchify_resize_kernel<hx2>, dim3(rows), dim3(256), lds, stream, a, *rs, (hx2*)Ape, x);
+        else if (p == PREC_F32)
             launch(patchify_resize_kernel<float>, dim3(rows), dim3(256), lds, stream, a, *rs, (float*)Ape, x);
         else if (p == PREC_F16)
             launch(patchify_resize_kernel<f16>, dim3(rows), dim3(256), lds, stream, a, *rs, (f16*)Ape, x);
@@ -137,7 +145,9 @@ int launch_patchify(Precision p, const PatchifyArgs& a, const ResizeArgs* rs, vo
             launch(patchify_resize_kernel<bf16>, dim3(rows), dim3(256), lds, stream, a, *rs, (bf16*)Ape, x);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    if (p == PREC_F32)
+    if (p == PREC_X2)
+        launch(patchify_kernel<hx2>, dim3(rows), dim3(256), 0, stream, a, (hx2*)Ape, x);
+    else if (p == PREC_F32)
         launch(patchify_kernel<float>, dim3(rows), dim3(256), 0, stream, a, (float*)Ape, x);
     else if (p == PREC_F16)
         launch(patchify_kernel<f16>, dim3(rows), dim3(256), 0, stream, a, (f16*)Ape, x);
@@ -181,7 +191,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const float y0 = (v[i].x - mean) * rstd * g.x + b.x;
         const float y1 = (v[i].y - mean) * rstd * g.y + b.y;
         T* dst = out + (size_t)row * D + 2 * (i * 64 + lane);
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (kSplit<T>) {
+            store_x2_one(out + (size_t)row * D * 2, 2 * (i * 64 + lane), y0);
+            store_x2_one(out + (size_t)row * D * 2, 2 * (i * 64 + lane) + 1, y1);
+        } else if constexpr (sizeof(T) == 4) {
             *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
         } else {
             typedef T t16x2 __attribute__((ext_vector_type(2)));
@@ -209,6 +222,7 @@ static int launch_ln_t(const float* x, const float* g, const float* b, T* out, i
 int launch_layernorm(Precision p, const float* x, const float* gamma, const float* beta, void* out, int M, int D,
                      float eps, hipStream_t stream) {
     if (M <= 0) return -2;
+    if (p == PREC_X2) return launch_ln_t<hx2>(x, gamma, beta, (hx2*)out, M, D, eps, stream);
     if (p == PREC_F32) return launch_ln_t<float>(x, gamma, beta, (float*)out, M, D, eps, stream);
     if (p == PREC_F16) return launch_ln_t<f16>(x, gamma, beta, (f16*)out, M, D, eps, stream);
     return launch_ln_t<bf16>(x, gamma, beta, (bf16*)out, M, D, eps, stream);
@@ -364,7 +378,10 @@ __global__ __launch_bounds__(64) void residual_ln_kernel(float* __restrict__ x, 
         const float y2 = (v[i].z - mean) * rstd * gg[i].z + be[i].z;
         const float y3 = (v[i].w - mean) * rstd * gg[i].w + be[i].w;
         T* dst = out + (size_t)row * D + 4 * (i * LANES + l);
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (kSplit<T>) {
+            if (wt) store_x2<true>(out + (size_t)row * D * 2, 4 * (i * LANES + l), f32x4{y0, y1, y2, y3});
+            else store_x2<false>(out + (size_t)row * D * 2, 4 * (i * LANES + l), f32x4{y0, y1, y2, y3});
+        } else if constexpr (sizeof(T) == 4) {
             if (wt) store_out<true>(dst, make_float4(y0, y1, y2, y3));
             else store_out<false>(dst, make_float4(y0, y1, y2, y3));
         } else {
@@ -397,6 +414,7 @@ template <int MODE>
 static int launch_rln_p(Precision p, float* x, const float* part, int splits, const float* bias, const float* ls,
                         const float* g, const float* b, void* out, int M, int D, float eps, hipStream_t stream,
                         const RlnExtra& ex) {
+    if (p == PREC_X2) return launch_rln_t<hx2, MODE>(x, part, splits, bias, ls, g, b, (hx2*)out, M, D, eps, stream, ex);
     if (p == PREC_F32) return launch_rln_t<float, MODE>(x, part, splits, bias, ls, g, b, (float*)out, M, D, eps, stream, ex);
     if (p == PREC_F16) return launch_rln_t<f16, MODE>(x, part, splits, bias, ls, g, b, (f16*)out, M, D, eps, stream, ex);
     return launch_rln_t<bf16, MODE>(x, part, splits, bias, ls, g, b, (bf16*)out, M, D, eps, stream, ex);
@@ -523,6 +541,18 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     for (int d = lane; d < Dp; d += 64) dst[(size_t)row * Dp + d] = __fdiv_rn(s[d], nrm);
 }
 
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, unsigned n16) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t stream) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0 || n16 >= (1ull << 32)) return -2;
+    const unsigned wgs = (unsigned)std::min<size_t>((n16 + 255) / 256, 1024);
+    launch(copy16_kernel, dim3(wgs), dim3(256), 0, stream, (const u32x4*)src, (u32x4*)dst, (unsigned)n16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream) {
     if (rows <= 0 || Dp <= 0) return -2;
     launch(normalize_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, src, dst, rows, Dp);
@@ -538,11 +568,12 @@ __global__ __launch_bounds__(256) void facet_kernel(const T* __restrict__ qkv, f
     const int rows = Tn + keep_cls;
     const int tok = blockIdx.x, img = tok / rows, t = tok - img * rows;
     const int D = H * 64;
-    const T* src = qkv + ((size_t)img * (Tn + 1) + (1 - keep_cls) + t) * 3 * D + (size_t)which * D;
+    const size_t qrow = (size_t)img * (Tn + 1) + (1 - keep_cls) + t;
     float* dst = out + (size_t)tok * D;
     for (int j = threadIdx.x; j < D; j += 256) {
         const int h = j % H, d = j / H;
-        dst[j] = (float)src[h * 64 + d] * unscale;
+        if constexpr (kSplit<T>) dst[j] = load_x2(qkv + qrow * 3 * D * 2, which * D + h * 64 + d) * unscale;
+        else dst[j] = (float)qkv[qrow * 3 * D + (size_t)which * D + h * 64 + d] * unscale;
     }
 }
 
@@ -551,7 +582,8 @@ int launch_facet(Precision p, const void* qkv, float* out, int n_img, int T, int
     if (n_img <= 0 || T <= 0 || H <= 0 || which < 0 || which > 2) return -2;
     const dim3 grid(n_img * (T + (keep_cls ? 1 : 0)));
     const int kc = keep_cls ? 1 : 0;
-    if (p == PREC_F32) launch(facet_kernel<float>, grid, dim3(256), 0, stream, (const float*)qkv, out, T, H, which, q_unscale, kc);
+    if (p == PREC_X2) launch(facet_kernel<hx2>, grid, dim3(256), 0, stream, (const hx2*)qkv, out, T, H, which, q_unscale, kc);
+    else if (p == PREC_F32) launch(facet_kernel<float>, grid, dim3(256), 0, stream, (const float*)qkv, out, T, H, which, q_unscale, kc);
     else if (p == PREC_F16) launch(facet_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)qkv, out, T, H, which, q_unscale, kc);
     else launch(facet_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)qkv, out, T, H, which, q_unscale, kc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -621,6 +653,7 @@ __global__ __launch_bounds__(256) void saliency_kernel(const T* __restrict__ qkv
 int launch_saliency(Precision p, const void* qkv, float* out, int n_img, int T, int H, const int* head_idx, int n_heads,
                     bool q_prescaled, hipStream_t stream) {
     if (n_img <= 0 || T <= 0 || H <= 0 || n_heads <= 0 || n_heads > 16) return -2;
+    if (p == PREC_X2) return -2;   // the saliency surface is frozen (outside SURVEY section 8): fp32 / bf16 / fp16 handles only
     SaliencyHeads hs;
     hs.n = n_heads;
     for (int i = 0; i < n_heads; ++i) {

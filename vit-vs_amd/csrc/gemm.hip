@@ -13,6 +13,7 @@ namespace vitvs {
 
 template <typename T, bool WT>
 __device__ __forceinline__ void store4(T* dst, f32x4 v) {
+    static_assert(!kSplit<T>, "f16x2 rows are addressed by logical column: store_x2");
     if constexpr (sizeof(T) == 4) {
         store_out<WT>(reinterpret_cast<float*>(dst), v);
     } else {
@@ -49,23 +50,26 @@ struct EpiStore {
     // staged epilogue (linear_kernel): the tile leaves through an LDS image as whole rows
     using Out = T;
     static constexpr bool STAGED = true;
+    // the fast erf is two orders below the output rounding of the plain 16-bit types only; f16x2 keeps fp32-class outputs
+    static constexpr bool FAST_GELU = sizeof(T) == 2 && !kSplit<T>;
+    static constexpr int OUT_BYTES = kSplit<T> ? 4 : (int)sizeof(T);     // bytes per logical output column
     __device__ __forceinline__ f32x4 value(f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 4; ++i) v[i] = FAST_GELU ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
         }
         return v;
     }
-    __device__ __forceinline__ T* row(int m) const { return out + (size_t)m * ldo; }
+    // first byte of logical column n0 (n0 % 32 == 0) of output row m
+    __device__ __forceinline__ unsigned char* row_bytes(int m, int n0) const {
+        return reinterpret_cast<unsigned char*>(out) + ((size_t)m * ldo + n0) * OUT_BYTES;
+    }
     template <bool WT>
     __device__ __forceinline__ void store(int m, int n, f32x4 v, float4 b) const {
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        if (gelu) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (sizeof(T) == 2) ? gelu_erf_fast(v[i]) : gelu_erf(v[i]);
-        }
-        store4<T, WT>(out + (size_t)m * ldo + n, v);
+        v = value(v, b);
+        if constexpr (kSplit<T>) store_x2<WT>(out + (size_t)m * ldo * 2, n, v);
+        else store4<T, WT>(out + (size_t)m * ldo + n, v);
     }
 };
 
@@ -127,8 +131,11 @@ struct EpiPartial {
     __device__ __forceinline__ void set_slice(int z) { part += (size_t)z * M * N; }
     using Out = float;
     static constexpr bool STAGED = true;
+    static constexpr int OUT_BYTES = 4;
     __device__ __forceinline__ f32x4 value(f32x4 v, float4) const { return v; }
-    __device__ __forceinline__ float* row(int m) const { return part + (size_t)m * N; }
+    __device__ __forceinline__ unsigned char* row_bytes(int m, int n0) const {
+        return reinterpret_cast<unsigned char*>(part + (size_t)m * N + n0);
+    }
     template <bool WT>
     __device__ __forceinline__ void store(int m, int n, f32x4 v, float4) const {
         store4<float, WT>(part + (size_t)m * N + n, v);
@@ -145,8 +152,10 @@ template <typename T, int BM, int BN, int KG, class Epi, int NS = 0>
 __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ A, const T* __restrict__ W, void* out,
                                                           const float* c0, const float* c1, int M, int N, int K,
                                                           int ks_i0) {
-    // ks_i0 packs [31:24] K per split-K slice / 32, [15:0] i0: one preloaded dword instead of gridDim (hidden kernel
-    // arguments the wave would have to fetch) and an integer division.
+    // ks_i0 packs [31:24] K per split-K slice in k-tiles of 32 (fp32) / 64 (two-byte types; f16x2: 32 logical k) elements,
+    // [23:19] e: f16x2 weights arrive multiplied by 2^e (api.hip upload_matrix), the sums leave multiplied by 2^-e,
+    // [18] staged epilogue, [16] XCD map, [15:0] i0: one preloaded dword instead of gridDim (hidden kernel arguments the
+    // wave would have to fetch) and an integer division.
 #ifdef VITVS_PROBE
     unsigned long long ts[8];
     ts[0] = __builtin_readcyclecounter();
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned pk = (unsigned)ks_i0;
-    const int kslice = (int)(pk >> 24) * 32;
+    const int kslice = (int)(pk >> 24) * (128 / (int)sizeof(T));
     int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
     if (pk & (1u << 16)) {
         // XCD map of the two-slice partial-sum launches (launch_one): a 1-D grid whose workgroup L runs on XCD L % 8; XCD x
@@ -184,6 +193,13 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
     ts[4] = __builtin_readcyclecounter();
 #endif
+    if constexpr (kSplit<T>) {
+        const float ws = __uint_as_float((127u - ((pk >> 19) & 31u)) << 23);   // 2^-e, exact
+#pragma unroll
+        for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] *= ws;
+    }
     if constexpr (BM == 64 && Epi::STAGED) {
         if (pk & (1u << 18)) {
             // Staged epilogue: a lane of the MFMA layout owns 4 consecutive columns of one row, so a wave's store instruction
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
             // LDS image (the ring is free: every wave is past its last k-tile) and leaves as 16-byte pieces of whole rows:
             // consecutive lanes write consecutive bytes, whole 128-byte lines.
             using Out = typename Epi::Out;
-            constexpr int ROWB = BN * (int)sizeof(Out), PITCH = ROWB + 16, CH = ROWB / 16;
+            constexpr int ROWB = BN * Epi::OUT_BYTES, PITCH = ROWB + 16, CH = ROWB / 16;
             // one k-group: the barrier ends the last k-tile's reads.  Two k-groups: the ring has been free since the barrier of
             // the accumulator swap (gemm_mainloop) unless the swap area itself lives in the ring; each group stages the tiles it owns.
             if constexpr (KG == 1 || Tile::SWAP_ALIAS) __syncthreads();
@@ -201,9 +217,14 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
                 for (int mi = 0; mi < Tile::MT; ++mi) {
                     if (KG == 2 && tile_owner<Tile::NT, Tile::MT>(ni, mi) != kg) continue;
                     const f32x4 v = epi.value(acc[ni][mi], col[ni]);
+                    const int cn = wn * Tile::WN + ni * 16 + 4 * (lane >> 4);      // tile-local column of v[0]
                     unsigned char* dst = smem + (wm * Tile::WM + mi * 16 + (lane & 15)) * PITCH +
-                                         (wn * Tile::WN + ni * 16 + 4 * (lane >> 4)) * (int)sizeof(Out);
-                    if constexpr (sizeof(Out) == 4) *reinterpret_cast<f32x4*>(dst) = v;
+                                         (kSplit<Out> ? 2 * x2_index(cn) : cn * (int)sizeof(Out));
+                    if constexpr (kSplit<Out>) {       // the image has the row layout of memory: [hi of 32 columns | lo of them]
+                        const Split4 h = split4(v);
+                        *reinterpret_cast<f16x4*>(dst) = h.hi;
+                        *reinterpret_cast<f16x4*>(dst + 64) = h.lo;
+                    } else if constexpr (sizeof(Out) == 4) *reinterpret_cast<f32x4*>(dst) = v;
                     else {
                         const typename Vec16<Out>::x4 h = {(Out)v[0], (Out)v[1], (Out)v[2], (Out)v[3]};
                         *reinterpret_cast<typename Vec16<Out>::x4*>(dst) = h;
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
                 const int r = idx / CH, ch = idx - r * CH;
                 if (m0 + r < M) {
                     const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * PITCH + ch * 16);
-                    store_out16<true>(reinterpret_cast<unsigned char*>(epi.row(m0 + r) + n0) + ch * 16, d);
+                    store_out16<true>(epi.row_bytes(m0 + r, n0) + ch * 16, d);
                 }
             }
             return;
@@ -250,10 +271,10 @@ extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_gemm_probe
 }
 #endif
 
-static int k_tile(Precision p) { return (p == PREC_F32) ? 32 : 64; }
+static int k_tile(Precision p) { return plain16(p) ? 64 : 32; }   // logical k per 128-byte k-tile (f16x2: 32, hi and lo halves)
 
 static bool shapes_ok(Precision p, int M, int N, int K) {
-    const long long es = (p == PREC_F32) ? 4 : 2;   // operands are addressed with 32-bit byte offsets
+    const long long es = (long long)elem_size(p);   // operands are addressed with 32-bit byte offsets
     return M > 0 && N > 0 && K > 0 && (K % k_tile(p)) == 0 && (N % 64) == 0 && (long long)M * K * es < (1ll << 32) &&
            (long long)N * K * es < (1ll << 32);
 }
@@ -293,6 +314,7 @@ struct EpiArgs {   // host image of the flat epilogue arguments
     const float* c0;
     const float* c1;
     int i0;
+    int wexp = 0;   // f16x2: the weights carry 2^wexp (linear_kernel)
 };
 
 // The XCD map (linear_kernel) is for the partial-sum launches only (their i0 field is unused, bit 16 of the packed argument is free)
@@ -318,8 +340,9 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
     static std::atomic<unsigned long long> raised{0};   // > 64 KiB of dynamic LDS needs the opt-in attribute, per device
     if (raise_lds_limit(reinterpret_cast<const void*>(&linear_kernel<T, BM, BN, KG, Epi, NS>), Tile::LDS_BYTES, raised)) return -1;
     dim3 grid(N / BN, (M + BM - 1) / BM, splits);
+    constexpr int KU = 128 / (int)sizeof(T);   // elements per k-tile (f16x2: K counts fp16, two per logical k)
     const int kslice = K / splits;
-    if (kslice % 32 != 0 || kslice / 32 > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff) return -2;
+    if (kslice % KU != 0 || kslice / KU > 255 || splits > 15 || e.i0 < 0 || e.i0 > 0xffff || e.wexp < 0 || e.wexp > 31) return -2;
     unsigned xcd_map = 0;
     if (xcd_mapped<Epi>() && splits == 2 && (N / BN) % 4 == 0 && want_xcd_map()) {
         grid = dim3(grid.x * grid.y * 2, 1, 1);
@@ -327,7 +350,7 @@ static int launch_one(const T* A, const T* W, int M, int N, int K, const EpiArgs
     }
     if (BM == 64 && want_staged_epilogue(KG)) xcd_map |= 1u << 18;
     launch(linear_kernel<T, BM, BN, KG, Epi, NS>, grid, dim3(Tile::THREADS), Tile::LDS_BYTES, stream, A, W, e.out, e.c0, e.c1,
-           M, N, K, (int)(((unsigned)(kslice / 32) << 24) | xcd_map | (unsigned)e.i0));
+           M, N, K, (int)(((unsigned)(kslice / KU) << 24) | ((unsigned)e.wexp << 19) | xcd_map | (unsigned)e.i0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -395,16 +418,17 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
 }
 
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                  int gelu, hipStream_t stream) {
+                  int gelu, hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K)) return -2;
     if (const int bn = big_tile_width(p, M, N, K, 1, false)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream);
-    return launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, stream);
+    return launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, stream, wexp);
 }
 
 int launch_linear_classic(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                          int gelu, hipStream_t stream) {
+                          int gelu, hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    const EpiArgs e{out, bias, nullptr, gelu};
+    const EpiArgs e{out, bias, nullptr, gelu, p == PREC_X2 ? wexp : 0};
+    if (p == PREC_X2) return launch_tiles<hx2, EpiStore<hx2>>((const hx2*)A, (const hx2*)W, M, N, 2 * K, e, stream);
     if (p == PREC_F32) return launch_tiles<float, EpiStore<float>>((const float*)A, (const float*)W, M, N, K, e, stream);
     if (p == PREC_F16) return launch_tiles<f16, EpiStore<f16>>((const f16*)A, (const f16*)W, M, N, K, e, stream);
     return launch_tiles<bf16, EpiStore<bf16>>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
@@ -413,7 +437,7 @@ int launch_linear_classic(Precision p, const void* A, const void* W, const float
 // experiments (vitvs_op_linear_variant 2): the 128 x 128 tiles of this file whatever the shape
 int launch_linear_128(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int gelu,
                       int splits, bool partial, hipStream_t stream) {
-    if (!shapes_ok(p, M, N, K) || N % 128 != 0 || p == PREC_F32) return -2;
+    if (!shapes_ok(p, M, N, K) || N % 128 != 0 || !plain16(p)) return -2;
     if (partial) {
         const EpiArgs e{out, nullptr, nullptr, 0};
         if (p == PREC_F16) return launch_one<f16, 128, 1, EpiPartial, 128>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
@@ -425,9 +449,10 @@ int launch_linear_128(Precision p, const void* A, const void* W, const float* bi
 }
 
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
-                           int M, int N, int K, hipStream_t stream) {
+                           int M, int N, int K, hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    const EpiArgs e{x, bias, ls, 0};
+    const EpiArgs e{x, bias, ls, 0, p == PREC_X2 ? wexp : 0};
+    if (p == PREC_X2) return launch_tiles64<hx2, EpiResidual>((const hx2*)A, (const hx2*)W, M, N, 2 * K, e, stream);
     if (p == PREC_F32) return launch_tiles64<float, EpiResidual>((const float*)A, (const float*)W, M, N, K, e, stream);
     if (p == PREC_F16) return launch_tiles64<f16, EpiResidual>((const f16*)A, (const f16*)W, M, N, K, e, stream);
     return launch_tiles64<bf16, EpiResidual>((const bf16*)A, (const bf16*)W, M, N, K, e, stream);
@@ -438,7 +463,7 @@ int splitk_slices(Precision p, int M, int N, int K) {
     // Many rows, narrow layer (8 frame pairs or a 518² input through proj / fc2): the 256x128 tiles of gemm_big.hip fill
     // well under half of the chip (78 tiles at 3152 x 768), so K is cut into the most slices that still fit one workgroup
     // per CU and leave >= 8 k-tiles per slice (3152 x 768 x 3072: 35 us on the tiles below -> 3 slices of 234 tiles).
-    if (p != PREC_F32 && M >= 1024 && N % 128 == 0) {
+    if (plain16(p) && M >= 1024 && N % 128 == 0) {
         const long t128 = (long)((M + 255) / 256) * (N / 128);
         if (t128 >= 96) return 1;
         int pick = 1;
@@ -467,17 +492,18 @@ int splitk_slices(Precision p, int M, int N, int K) {
 }
 
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
-                          hipStream_t stream) {
+                          hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
     if (const int bn = big_tile_width(p, M, N, K, splits, true))
         return launch_linear_big(p, bn, A, W, nullptr, part, M, N, K, splits, 0, true, stream);
-    return launch_linear_partial_classic(p, A, W, part, M, N, K, splits, stream);
+    return launch_linear_partial_classic(p, A, W, part, M, N, K, splits, stream, wexp);
 }
 
 int launch_linear_partial_classic(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
-    const EpiArgs e{part, nullptr, nullptr, 0};
+    const EpiArgs e{part, nullptr, nullptr, 0, p == PREC_X2 ? wexp : 0};
+    if (p == PREC_X2) return launch_tiles64<hx2, EpiPartial>((const hx2*)A, (const hx2*)W, M, N, 2 * K, e, stream, splits);
     if (p == PREC_F32) return launch_tiles64<float, EpiPartial>((const float*)A, (const float*)W, M, N, K, e, stream, splits);
     if (p == PREC_F16) return launch_tiles64<f16, EpiPartial>((const f16*)A, (const f16*)W, M, N, K, e, stream, splits);
     return launch_tiles64<bf16, EpiPartial>((const bf16*)A, (const bf16*)W, M, N, K, e, stream, splits);
@@ -496,10 +522,11 @@ int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial,
 }
 
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
-                       int n_img, int T, int D, int Kp, hipStream_t stream) {
+                       int n_img, int T, int D, int Kp, hipStream_t stream, int wexp) {
     const int M = n_img * T;
     if (!shapes_ok(p, M, D, Kp)) return -2;
-    const EpiArgs e{x, bias, pos, T};
+    const EpiArgs e{x, bias, pos, T, p == PREC_X2 ? wexp : 0};
+    if (p == PREC_X2) return launch_tiles64<hx2, EpiPatch>((const hx2*)Ape, (const hx2*)Wpe, M, D, 2 * Kp, e, stream);
     if (p == PREC_F32) return launch_tiles64<float, EpiPatch>((const float*)Ape, (const float*)Wpe, M, D, Kp, e, stream);
     if (p == PREC_F16) return launch_tiles64<f16, EpiPatch>((const f16*)Ape, (const f16*)Wpe, M, D, Kp, e, stream);
     return launch_tiles64<bf16, EpiPatch>((const bf16*)Ape, (const bf16*)Wpe, M, D, Kp, e, stream);

@@ -476,7 +476,7 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
 // end: ~8 us at 6274 x 2304) — the rule below is that model with the relative tile costs measured.
 // Returns 0 (use gemm.hip), the column width 256, 192 or 128 of a 256-row tile, or 1192 / 1256 for the 192 x 128 / 192 x 256 tile.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
-    if (p == PREC_F32 || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
+    if (!plain16(p) || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
     // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
     // 11.9 us on 256 x 128 tiles); where they need a second round the 256-row tiles win from 64 tiles up (985 x 2304: 18.4 vs
     // 11.9 us).  Between the tile families of this file the busiest CU's share decides (below).

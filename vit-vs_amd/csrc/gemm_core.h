@@ -18,6 +18,8 @@
 //
 //   f32 : v_mfma_f32_16x16x4_f32   (exact fp32 FMA chain, 4 per 16-byte chunk pair)
 //   bf16: v_mfma_f32_16x16x32_bf16 (one per 16-byte chunk pair), fp32 accumulate; fp16: v_mfma_f32_16x16x32_f16, the same
+//   f16x2 (hx2, common.h): rows hold [hi of 32 k | lo of the same 32 k] per 128 bytes; three v_mfma_f32_16x16x32_f16 per
+//         k-tile and accumulator (hi.hi + hi.lo + lo.hi): fp32-class sums at 16-bit MFMA rate, operand bytes as fp32
 #pragma once
 #include "common.h"
 
@@ -156,22 +158,54 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
         if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
         const unsigned char* sa = ring + stage * Tile::STAGE_BYTES;
         const unsigned char* sb = sa + BM * 128;
+        if constexpr (kSplit<T>) {
+            // f16x2: chunks 0-3 of the 128-byte k-tile hold the hi halves of 32 k, chunks 4-7 the lo halves (common.h).  One
+            // k-step of 32: lo.hi + hi.lo first (the small terms), then hi.hi; the dropped lo.lo is < 2^-22 of the product.
+            // Term-outer order: the three MFMAs into one accumulator are NT x MT - 1 independent MFMAs apart.
+            const int g = lane >> 4;
+            u32x4 wh[Tile::NT], wl[Tile::NT], xh[Tile::MT], xl[Tile::MT];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int c = 4 * s + (lane >> 4);
-            u32x4 wf[Tile::NT], xf[Tile::MT];
+            for (int ni = 0; ni < Tile::NT; ++ni) {
+                const int r = wn * Tile::WN + ni * 16 + (lane & 15);
+                wh[ni] = *reinterpret_cast<const u32x4*>(sb + tile128_off(r, g));
+                wl[ni] = *reinterpret_cast<const u32x4*>(sb + tile128_off(r, 4 + g));
+            }
+#pragma unroll
+            for (int mi = 0; mi < Tile::MT; ++mi) {
+                const int r = wm * Tile::WM + mi * 16 + (lane & 15);
+                xh[mi] = *reinterpret_cast<const u32x4*>(sa + tile128_off(r, g));
+                xl[mi] = *reinterpret_cast<const u32x4*>(sa + tile128_off(r, 4 + g));
+            }
 #pragma unroll
             for (int ni = 0; ni < Tile::NT; ++ni)
-                wf[ni] = *reinterpret_cast<const u32x4*>(sb + tile128_off(wn * Tile::WN + ni * 16 + (lane & 15), c));
 #pragma unroll
-            for (int mi = 0; mi < Tile::MT; ++mi)
-                xf[mi] = *reinterpret_cast<const u32x4*>(sa + tile128_off(wm * Tile::WM + mi * 16 + (lane & 15), c));
+                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = mma_chunk<f16>(acc[ni][mi], wl[ni], xh[mi]);
 #pragma unroll
             for (int ni = 0; ni < Tile::NT; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < Tile::MT; ++mi) {
-                    acc[ni][mi] = mma_chunk<T>(acc[ni][mi], wf[ni], xf[mi]);
-                }
+                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = mma_chunk<f16>(acc[ni][mi], wh[ni], xl[mi]);
+#pragma unroll
+            for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < Tile::MT; ++mi) acc[ni][mi] = mma_chunk<f16>(acc[ni][mi], wh[ni], xh[mi]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c = 4 * s + (lane >> 4);
+                u32x4 wf[Tile::NT], xf[Tile::MT];
+#pragma unroll
+                for (int ni = 0; ni < Tile::NT; ++ni)
+                    wf[ni] = *reinterpret_cast<const u32x4*>(sb + tile128_off(wn * Tile::WN + ni * 16 + (lane & 15), c));
+#pragma unroll
+                for (int mi = 0; mi < Tile::MT; ++mi)
+                    xf[mi] = *reinterpret_cast<const u32x4*>(sa + tile128_off(wm * Tile::WM + mi * 16 + (lane & 15), c));
+#pragma unroll
+                for (int ni = 0; ni < Tile::NT; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < Tile::MT; ++mi) {
+                        acc[ni][mi] = mma_chunk<T>(acc[ni][mi], wf[ni], xf[mi]);
+                    }
+            }
         }
         stage = (stage + 1 == NST) ? 0 : stage + 1;
     }

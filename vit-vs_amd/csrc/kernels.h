@@ -57,32 +57,37 @@ inline int raise_lds_limit(const void* fn, int bytes, std::atomic<unsigned long 
     return 0;
 }
 
-enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };   // operand type of the GEMMs / attention; fp32 accumulate
+// operand type of the GEMMs / attention; fp32 accumulate.  PREC_X2 = split-f16 (common.h hx2): every operand is an fp16
+// hi / lo pair, rows are [hi of 32 columns | lo of the same 32] per 64 fp16, three f16 MFMAs per k-step: fp32-class results
+enum Precision : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_X2 = 3 };
 
-inline size_t elem_size(Precision p) { return p == PREC_F32 ? 4 : 2; }
+inline size_t elem_size(Precision p) { return (p == PREC_F32 || p == PREC_X2) ? 4 : 2; }   // bytes per LOGICAL element
+inline bool plain16(Precision p) { return p == PREC_BF16 || p == PREC_F16; }
 
 // ---- gemm.hip ------------------------------------------------------------------------------
 // out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]); A, W, out in precision p; gelu: erf GELU.
+// wexp (PREC_X2 only, 0 .. 31): W holds the weights times 2^wexp (so that their lo halves are normal fp16 numbers); the
+// kernel multiplies the sums by 2^-wexp before the epilogue.
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                  int gelu, hipStream_t stream);
+                  int gelu, hipStream_t stream, int wexp = 0);
 // the same two operators restricted to the tiles of gemm.hip (no hand-over to gemm_big.hip)
 int launch_linear_128(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int gelu,
                       int splits, bool partial, hipStream_t stream);
 int launch_linear_classic(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                          int gelu, hipStream_t stream);
+                          int gelu, hipStream_t stream, int wexp = 0);
 int launch_linear_partial_classic(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int wexp = 0);
 // x[m][n] += ls[n] * (sum_k A[m][k] W[n][k] + bias[n]); x fp32 residual stream, ls may be null.
 int launch_linear_residual(Precision p, const void* A, const void* W, const float* bias, const float* ls, float* x,
-                           int M, int N, int K, hipStream_t stream);
+                           int M, int N, int K, hipStream_t stream, int wexp = 0);
 // Split-K form for the narrow (N = D) layers: part[z][m][n] = sum over K slice z of A[m][k] W[n][k], fp32,
 // z < splits (splitk_slices picks the count); finished by launch_residual_ln.
 int splitk_slices(Precision p, int M, int N, int K);
 int launch_linear_partial(Precision p, const void* A, const void* W, float* part, int M, int N, int K, int splits,
-                          hipStream_t stream);
+                          hipStream_t stream, int wexp = 0);
 // x[img*(T+1) + 1 + t][n] = sum_k Ape[img*T + t][k] Wpe[n][k] + bias[n] + pos[1 + t][n]
 int launch_patch_embed(Precision p, const void* Ape, const void* Wpe, const float* bias, const float* pos, float* x,
-                       int n_img, int T, int D, int Kp, hipStream_t stream);
+                       int n_img, int T, int D, int Kp, hipStream_t stream, int wexp = 0);
 
 // ---- gemm_big.hip: 256-row tiles for many-row problems (16-bit operands) --------------------------------
 // big_tile_width: 0 = not applicable (use the tiles of gemm.hip), else the tile code to pass on: the column width 256, 192 or 128 of a
@@ -149,6 +154,11 @@ int launch_embed_ln(Precision p, float* x, const float* part, int splits, const 
 int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, int n_img, int T, int grid, int D,
                        int binned, unsigned long long* zero_a, unsigned long long* zero_b, int zero_count,
                        hipStream_t stream);
+
+// dst[0 .. bytes) = src[0 .. bytes), 16 bytes per lane (both buffers hold a multiple of 16 bytes): the host-pointer entry point's
+// in-stream copy of caller frames from the handle's pinned staging memory (device-visible host memory) to device memory —
+// one short launch on the update's own stream instead of a copy-engine command and its queue hops.
+int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t stream);
 
 // dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);

@@ -39,8 +39,10 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self.params = params or ServoParams(dino_input_size=cfg.img_size)
-        self.precision = {"fp32": _lib.F32, "f32": _lib.F32, "bf16": _lib.BF16, "fp16": _lib.F16, "f16": _lib.F16}[precision]
-        self.precision_name = {_lib.F32: "fp32", _lib.BF16: "bf16", _lib.F16: "fp16"}[self.precision]
+        # "f16x2": split-f16 (include/vitvs.h VITVS_F16X2) — fp32-class results on the f16 matrix cores, the parity mode at servo rate
+        self.precision = {"fp32": _lib.F32, "f32": _lib.F32, "bf16": _lib.BF16, "fp16": _lib.F16, "f16": _lib.F16,
+                          "f16x2": _lib.F16X2, "split-f16": _lib.F16X2}[precision]
+        self.precision_name = {_lib.F32: "fp32", _lib.BF16: "bf16", _lib.F16: "fp16", _lib.F16X2: "f16x2"}[self.precision]
         self.binned = self.params.use_feature_binning if binned is None else bool(binned)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_pairs = int(max_pairs)
@@ -324,6 +326,68 @@ class Engine:
         k = self._num_pairs(num_pairs)
         sel, cnt = self._selection_args(mode, selection, n, self.tokens, k)
         return self.compute_velocity_dev(cur, des, z, kk, mode, sel, cnt, des_shared, num_pairs=k)
+
+    def compute_velocity_host(self, I_cur, I_des, Z, K, mode: int = _lib.SELECT_DENSE, selection=None, n_selected=None,
+                              des_shared: bool = False, num_pairs: Optional[int] = None):
+        """The host-pointer entry point (``vitvs_compute_velocity``): numpy arrays in — uint8 frames [n, H, W, 3] in the
+        engine's current frame geometry, uint16 depth [n, v_max, u_max] (or None), intrinsics [n, 4] or [4], an int32
+        selection laid out for ``mode`` — numpy ``(v_c [n, 6] float64, status [n] int32)`` out, ONE synchronous C call: what
+        the reference's ``detect_features`` + ``ibvs`` do per update with the arrays its callbacks hold
+        (vitvs_v2.py:464-523, 588-632).  No torch tensor is created on this path."""
+        cur = np.ascontiguousarray(I_cur, dtype=np.uint8)
+        if cur.ndim == 3:
+            cur = cur[None]
+        n = cur.shape[0]
+        des = None
+        if I_des is not None:
+            des = np.ascontiguousarray(I_des, dtype=np.uint8)
+            if des.ndim == 3:
+                des = des[None]
+            if des.shape[0] != (1 if des_shared else n) or des.shape[1:] != cur.shape[1:]:
+                raise VitvsError("I_des must hold one frame per pair (or one frame when des_shared), in the geometry of I_cur")
+        if tuple(cur.shape[1:3]) != tuple(self.frame_size) or cur.shape[3] != 3:
+            raise VitvsError(f"frames are {tuple(cur.shape[1:])}, the engine expects {tuple(self.frame_size)} x 3 (set_frame_size)")
+        z = None
+        if Z is not None:
+            z = np.ascontiguousarray(Z)
+            if z.dtype != np.uint16 or z.size != n * self.params.v_max * self.params.u_max:
+                raise VitvsError("Z must be the sensor's uint16 millimetre image(s) [v_max, u_max]")
+        kk = np.ascontiguousarray(np.broadcast_to(np.asarray(K, np.float64).reshape(-1, 4), (n, 4)))
+        k = self._num_pairs(num_pairs)
+        sel = cnt = None
+        if mode == _lib.SELECT_EXPLICIT:
+            rows = selection if isinstance(selection, (list, tuple)) else [selection]
+            if len(rows) != n:
+                raise VitvsError("one id list per pair expected")
+            sel = np.zeros((n, k), np.int32)
+            cnt = np.zeros(n, np.int32)
+            for b, ids in enumerate(rows):
+                ids = np.asarray(ids, np.int32).reshape(-1)[:k]
+                sel[b, :ids.size] = ids
+                cnt[b] = ids.size
+        elif mode == _lib.SELECT_ORDER:
+            sel = np.ascontiguousarray(np.asarray(selection, np.int32).reshape(n, self.tokens))
+        v = np.zeros((n, 6), np.float64)
+        st = np.zeros(n, np.int32)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.vitvs_compute_velocity(self.handle, n, p(cur), p(des), int(des_shared), p(z), p(kk), mode, p(sel), p(cnt), k,
+                                             p(v), p(st))
+        self._check(rc, "vitvs_compute_velocity")
+        self._last_tokens = self.tokens
+        return v, st
+
+    def last_features(self, n_pairs: int = 1) -> dict:
+        """``info``, ``s_uv`` and ``feat`` of the last servo call — what ``detect_features`` returns is made of
+        (vitvs_v2.py:511-553) — without the arg-max tables and ``L_e`` that ``last_details`` also fetches.  After
+        ``compute_velocity_host`` they are already in host memory (the handle's pinned block): no device call at all."""
+        r = self.max_rows
+        info = np.empty((n_pairs, 8), np.int32)
+        suv = np.empty((n_pairs, r, 4), np.int32)
+        feat = np.empty((n_pairs, r, 4), np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.vitvs_last_details(self.handle, n_pairs, None, None, None, p(info), None, p(suv), p(feat), None)
+        self._check(rc, "vitvs_last_details")
+        return dict(info=info, s_uv=suv, feat=feat)
 
     # ------------------------------------------------------------------ options
     def set_option(self, name: str, value: int) -> "Engine":

@@ -187,6 +187,8 @@ class Controller:
         self.velocity_vector_history = []
         self.max_velocity_vector_history = 200            # config.yaml:37
         self.last_status = None
+        self.generator = None                             # torch.Generator of the "order" draws (None: torch's global RNG)
+        self._rejected_geometries = set()                 # camera geometries the fused resize refused (set_frame_size), per engine
 
     # -- inputs (the reference's ROS callbacks)
     def image_callback_rgb(self, rgb_u8):
@@ -219,15 +221,17 @@ class Controller:
                 img = np.asarray(img.convert("RGB"), dtype=np.uint8)
             arrs.append(img if torch.is_tensor(img) else np.asarray(img, dtype=np.uint8))
         shapes = {tuple(a.shape[:2]) for a in arrs}
-        if len(shapes) == 1:
+        if len(shapes) == 1 and next(iter(shapes)) not in self._rejected_geometries:
+            shape = shapes.pop()
             try:
-                self.engine.set_frame_size(*shapes.pop())
+                self.engine.set_frame_size(*shape)
                 return arrs
             except VitvsError:
                 # a geometry the fused resize cannot take (too many camera rows per patch for its LDS rows, or no memory for
                 # the staging buffers): the engine kept its previous geometry (vitvs_set_frame_size changes nothing on
-                # failure); fall back to the stand-alone resize launch below
-                pass
+                # failure); fall back to the stand-alone resize launch below — and do not ask again for this geometry: every
+                # attempt builds Pillow's tables, allocates and synchronises the device
+                self._rejected_geometries.add(shape)
         self.engine.set_frame_size()
         return [self._resized(a) for a in arrs]
 
@@ -241,11 +245,25 @@ class Controller:
         depth = self.latest_image_depth
         # the law needs a depth image; detect_features itself does not, so feed a dummy one if it is missing
         z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
-        v, st = compute_velocity(self.engine, cur, des, z, self.params.intrinsics(), selection=self.selection,
-                                 num_pairs=self.num_pairs)
+        eng = self.engine
+        if isinstance(self.selection, str) and self.selection in ("order", "dense") and not torch.is_tensor(cur) \
+                and not torch.is_tensor(des) and tuple(cur.shape[:2]) == tuple(eng.frame_size) and np.asarray(z).dtype == np.uint16:
+            # the callbacks' own arrays straight into the host-pointer entry point: one C call, no torch tensor, the feature
+            # rows come back with it (Engine.last_features reads them from the handle's pinned block)
+            if self.selection == "order":
+                order = torch.randperm(eng.tokens, generator=self.generator).to(torch.int32).numpy()
+                v, st = eng.compute_velocity_host(cur, des, z, self.params.intrinsics(), _lib.SELECT_ORDER, order,
+                                                  num_pairs=self.num_pairs)
+            else:
+                v, st = eng.compute_velocity_host(cur, des, z, self.params.intrinsics(), _lib.SELECT_DENSE, num_pairs=self.num_pairs)
+            if not self._absorb(v[0], int(st[0])):
+                return None, None
+            return self._features(eng.last_features(1), 0)
+        v, st = compute_velocity(eng, cur, des, z, self.params.intrinsics(), selection=self.selection,
+                                 generator=self.generator, num_pairs=self.num_pairs)
         if not self._absorb(v, st):
             return None, None
-        return self._features(self.engine.last_details(1), 0)
+        return self._features(eng.last_features(1), 0)
 
     def _absorb(self, v, st) -> bool:
         """Bookkeeping of one finished update (whoever computed it: this controller's engine, or a ``MultiController``'s batched
@@ -397,13 +415,14 @@ class MultiController:
         cur = self._arrays([self.cameras[i].latest_pil_image for i in live])
         des = self._arrays([self.cameras[i].goal_image for i in live])
         shapes = {tuple(a.shape[:2]) for a in cur + des}
-        if len(shapes) == 1:
+        ctl0 = self.cameras[0]
+        if len(shapes) == 1 and next(iter(shapes)) not in ctl0._rejected_geometries:
             try:
                 for e in self.engines:
                     e.set_frame_size(*next(iter(shapes)))
                 return cur, des
             except VitvsError:
-                pass
+                ctl0._rejected_geometries.add(next(iter(shapes)))   # (see Controller._path_frames: never retried per step)
         for e in self.engines:
             e.set_frame_size()
         ctl = self.cameras[0]
@@ -434,24 +453,37 @@ class MultiController:
             v, st = eng.compute_velocity(stack(cur), stack(des), np.stack(depth), p.intrinsics(), mode=mode,
                                          selection=(torch.stack(sel) if mode == _lib.SELECT_ORDER else sel), num_pairs=k)
             v, st = v.cpu().numpy(), st.cpu().numpy()
-            det = eng.last_details(len(live)) if want_features else None
+            det = eng.last_features(len(live)) if want_features else None
+            failure = None
             for j, i in enumerate(live):
-                ok = self.cameras[i]._absorb(v[j], int(st[j]))
+                # a camera's 10th consecutive failure raises (vitvs_v2.py:500-505) — after EVERY camera of the round has been
+                # absorbed: N independent Controllers would each have taken their own step
+                try:
+                    ok = self.cameras[i]._absorb(v[j], int(st[j]))
+                except RuntimeError as exc:
+                    failure, ok = failure or exc, False
                 if want_features:
                     results[i] = self.cameras[i]._features(det, j) if ok else (None, None)
                 self.cameras[i]._law_step(ok)
+            if failure is not None:
+                raise failure
             return results if want_features else None
         # pipeline: `depth` cameras in flight at a time; a slot's outputs are read before the slot is used again
         pipe, dev = self.pipe, eng.device
         pending = []
+        failures = []
 
         def collect(upto):
             while len(pending) > upto:
                 i, t = pending.pop(0)
                 v, st = pipe.result(t)
-                ok = self.cameras[i]._absorb(v.cpu().numpy()[0], int(st[0]))
+                try:
+                    ok = self.cameras[i]._absorb(v.cpu().numpy()[0], int(st[0]))
+                except RuntimeError as exc:               # raised once the round is complete and nothing is in flight (below)
+                    failures.append(exc)
+                    ok = False
                 if want_features:
-                    results[i] = self.cameras[i]._features(pipe.engines[t % pipe.depth].last_details(1), 0) if ok else (None, None)
+                    results[i] = self.cameras[i]._features(pipe.engines[t % pipe.depth].last_features(1), 0) if ok else (None, None)
                 self.cameras[i]._law_step(ok)
 
         for j, i in enumerate(live):
@@ -482,6 +514,9 @@ class MultiController:
             collect(pipe.depth - 1)
             pending.append((i, pipe.submit(c_, d_, z_, k_, mode, s_, n_, False, k)))
         collect(0)
+        if failures:
+            pipe.synchronize()                            # no slot still reads the cameras' input buffers when the caller sees it
+            raise failures[0]
         return results if want_features else None
 
     def detect_features(self):
