@@ -142,6 +142,7 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
     are printed, and the exit code is 1 — a dead rank never leaves the others waiting in a collective until a time limit
     kills the whole job without a cause on record.  An overall deadline (VITVS_BENCH_DEADLINE_S, default 900 s) bounds
     the run the same way."""
+    import signal
     import tempfile
     n = args.gpus
     share = os.environ.get("VITVS_BENCH_SHARE_GPU") == "1"     # rehearsal: N ranks on fewer GPUs (gloo)
@@ -165,12 +166,31 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
         fh.seek(0)
         return "".join(fh.readlines()[-lines:])
 
+    watched = (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)
+
+    class _masked:
+        """The launcher's signals held back (pthread_sigmask) for a few lines that must not be torn: a rank's start + its entry in
+        `procs` (a signal between the two would leave a rank nobody ends: it runs in a session of its own), and `stop_all`."""
+        def __enter__(self):
+            try:
+                self.old = signal.pthread_sigmask(signal.SIG_BLOCK, watched)
+            except (ValueError, OSError, AttributeError):
+                self.old = None
+        def __exit__(self, *exc):
+            if self.old is not None:
+                signal.pthread_sigmask(signal.SIG_SETMASK, self.old)     # a signal that arrived meanwhile is delivered here
+            return False
+
+    stopped = []
+
     def stop_all():
         """Every rank runs in a session of its own (so that a signal aimed at this launcher's group cannot take a rank down
         half-way through a collective while the others wait): ending them is therefore this process's job on EVERY way out —
         a failed rank, the deadline, SIGTERM / SIGINT to the launcher, an exception.  SIGTERM to each rank's process group,
-        SIGKILL after 5 s."""
-        import signal
+        SIGKILL after 5 s.  Idempotent; the caller holds the launcher's signals back while it runs."""
+        if stopped:
+            return
+        stopped.append(True)
         for p_ in procs:
             if p_.poll() is None:
                 try:
@@ -194,9 +214,8 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
     def on_signal(signum, _frame):
         raise _Signalled(signum)
 
-    import signal
     previous = {}
-    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    for sig in watched:
         try:
             previous[sig] = signal.signal(sig, on_signal)
         except (ValueError, OSError):                      # not the main thread (the unit tests call this function directly)
@@ -206,8 +225,9 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
         for r, env in enumerate(envs):
             outs.append(open(os.path.join(logdir, f"rank{r}.out"), "w+"))
             errs.append(open(os.path.join(logdir, f"rank{r}.err"), "w+"))
-            procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                          stdout=outs[r], stderr=errs[r], text=True, start_new_session=True))
+            with _masked():                                 # started and on record, or not started: never in between
+                procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                              stdout=outs[r], stderr=errs[r], text=True, start_new_session=True))
         t_stop = time.monotonic() + deadline_s
         failed = None
         while True:
@@ -251,7 +271,8 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
         rc = 128 + int(sig.args[0])
         return rc
     finally:
-        stop_all()                                          # no rank outlives the launcher, whichever way it leaves
+        with _masked():
+            stop_all()                                      # no rank outlives the launcher, whichever way it leaves
         for fh in outs + errs:
             try:
                 fh.close()
@@ -270,9 +291,12 @@ def launch_ranks(args, argv, script=None, deadline_s=None, poll_s=0.2) -> int:
 
 
 # ----------------------------------------------------------------------------------------------- work model
-def split_k(m, n, k, bk, in_flight=1):
-    """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip (bk = 64 for the 16-bit precisions, 32 for fp32)."""
-    if bk == 64 and m >= 1024 and n % 128 == 0:
+def split_k(m, n, k, bk, in_flight=1, big_tiles=None):
+    """Mirror of splitk_slices() in vit-vs_amd/csrc/gemm.hip (bk = logical k per k-tile: 64 for the 16-bit precisions, 32 for fp32
+    and f16x2; big_tiles = the precision has the 256-row tiles of gemm_big.hip: everything but fp32)."""
+    if big_tiles is None:
+        big_tiles = bk == 64
+    if big_tiles and m >= 1024 and n % 128 == 0:
         t128 = -(-m // 256) * (n // 128)
         if t128 >= 96:
             return 1
@@ -292,16 +316,16 @@ def split_k(m, n, k, bk, in_flight=1):
     return min(best, 2) if in_flight >= 2 else best     # beside other queues' launches: at most two slices
 
 
-def kernel_work(cfg, n_img, n_pairs, es, binned, in_flight=1):
+def kernel_work(cfg, n_img, n_pairs, es, binned, in_flight=1, big_tiles=None):
     """Algorithmic FLOPs and minimum HBM bytes per LAUNCH of each kernel class."""
     n, t, d, h = cfg.seq, cfg.tokens, cfg.dim, cfg.hidden
     m = n_img * n
     bk = 128 // es
-    s_proj, s_fc2 = split_k(m, d, d, bk, in_flight), split_k(m, d, h, bk, in_flight)
+    s_proj, s_fc2 = split_k(m, d, d, bk, in_flight, big_tiles), split_k(m, d, h, bk, in_flight, big_tiles)
     s_avg = (s_proj + s_fc2) / 2
     dp = d * (9 if binned else 1)
     kp = -(-cfg.patch_k // 64) * 64
-    s_pe = split_k(n_img * t, d, kp, bk, in_flight)
+    s_pe = split_k(n_img * t, d, kp, bk, in_flight, big_tiles)
     return {
         "patchify": (0.0, n_img * cfg.img_size ** 2 * 3 + n_img * t * kp * es),
         # split-K patch embedding, finished (with cls / pos_embed / block 0's norm1) by the "layernorm" class
@@ -820,15 +844,15 @@ def run_rank(args):
         plain = None
         if rank == 0 and world == 1 and not args.no_plain_chain:   # single-process extra; ranks stay in lock step at N > 1
             m_rows, bk_ = 2 * B * cfg.seq, 128 // ELEM_BYTES[args.precision]
-            plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_, in_flight), dev)
+            plain = {name: plain_chain_us(args.precision, m_rows, cfg.dim, kk, split_k(m_rows, cfg.dim, kk, bk_, in_flight, args.precision != "fp32"), dev)
                      for name, kk in (("proj", cfg.dim), ("fc2", cfg.hidden))}
 
         overlapped = None
         if rank == 0 and world == 1 and not args.no_plain_chain and in_flight > 1:
             m_rows, bk_ = 2 * B * cfg.seq, 128 // ELEM_BYTES[args.precision]
             try:                                     # an auxiliary figure: it must never cost the line
-                overlapped = overlapped_chain_us(args.precision, m_rows, cfg.dim, cfg.hidden, split_k(m_rows, cfg.dim, cfg.dim, bk_, in_flight),
-                                                 split_k(m_rows, cfg.dim, cfg.hidden, bk_, in_flight), dev, queues=in_flight)
+                overlapped = overlapped_chain_us(args.precision, m_rows, cfg.dim, cfg.hidden, split_k(m_rows, cfg.dim, cfg.dim, bk_, in_flight, args.precision != "fp32"),
+                                                 split_k(m_rows, cfg.dim, cfg.hidden, bk_, in_flight, args.precision != "fp32"), dev, queues=in_flight)
             except Exception as exc:                 # noqa: BLE001
                 print(f"bench.py: roofline.overlapped not measured ({type(exc).__name__}: {exc})", file=sys.stderr)
                 torch.cuda.synchronize(dev)
@@ -985,7 +1009,8 @@ def run_rank(args):
     updates = world * B * args.steps
     value = updates / elapsed
     es = ELEM_BYTES[args.precision]
-    work = kernel_work(cfg, 2 * B, B, es, binned, in_flight)
+    big_rule = args.precision != "fp32"
+    work = kernel_work(cfg, 2 * B, B, es, binned, in_flight, big_rule)
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt == 0:
@@ -1037,7 +1062,7 @@ def run_rank(args):
         return f"attention_16_kernel<{tag}>"
     m_all = 2 * B * cfg.seq
     bk_es = 128 // es
-    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es, in_flight), True),
+    symbol = {"linear_partial(proj+fc2)": linear_symbol(m_all, cfg.dim, cfg.hidden, split_k(m_all, cfg.dim, cfg.hidden, bk_es, in_flight, big_rule), True),
               "residual_ln": f"residual_ln_kernel<{prec_tag}>",
               "fc1": linear_symbol(m_all, cfg.hidden, cfg.dim, 1, False),
               "qkv": linear_symbol(m_all, 3 * cfg.dim, cfg.dim, 1, False),

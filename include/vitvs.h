@@ -131,6 +131,24 @@ VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uin
                            int32_t des_shared, const uint16_t* Z_mm, const double* K, int32_t select_mode,
                            const int32_t* selection, const int32_t* n_selected, int32_t num_pairs, double* v_c,
                            int32_t* status);
+/* The host-pointer form is the reference's seam as it is called (numpy arrays in, a numpy twist out: vitvs_v2.py:464-523,
+ * 588-632).  Per call the buffers are copied into a block of pinned, device-visible host memory the handle owns (plain memcpy):
+ * the frames go on to device memory in one short copy launch each on the update's own stream, the depth image is copied after the
+ * forward has been enqueued and read in place by the law's kernel (<= max_rows pixels), and the twist, the status and the detail
+ * block (vitvs_last_details: everything but `selected` and `L`) are written into the pinned block by the device: one polled
+ * wait, no copy-engine command.  Option "reuse_goal_frames" (vitvs_set_option, 0 / 1, default 0): while I_des repeats the
+ * previous call's ADDRESS (and frame count and geometry) the goal frames already staged in device memory are forwarded again as
+ * they are — for callers that keep the goal image in a buffer they never write to (a servo loop's goal image is fixed:
+ * vitvs_v2.py:264); the goal's tokens are still recomputed on every update, like the reference does.
+ *
+ * vitvs_reselect: the reference draws its features on the HOST between the correspondence and the law
+ * (find_correspondences_batch: sort + torch.randperm, vitvs_v2.py:127-141).  After a host-pointer velocity call the tables are
+ * in host memory (vitvs_last_details: nn_1, nn_2, sim_1); the caller draws, and this entry point evaluates the law for that
+ * selection on what the call left in the handle (arg-max keys on the device, depth image and intrinsics in the pinned block):
+ * one launch, no forward, no staging.  selection / n_selected / num_pairs as in vitvs_compute_velocity; error -5 unless the
+ * handle's last velocity call was a host-pointer one. */
+VITVS_API int vitvs_reselect(vitvs_handle* h, int32_t select_mode, const int32_t* selection, const int32_t* n_selected,
+                             int32_t num_pairs, double* v_c, int32_t* status);
 
 /* --- a goal image that does not change between updates ---------------------------------------------
  * The reference recomputes the goal image's tokens on every update (vitvs_v2.py:482-487), and so does the call above
@@ -211,7 +229,8 @@ VITVS_API int vitvs_servo_from_nn_dev(vitvs_handle* h, int32_t T, const int32_t*
  * A call's law uses n_feature_rows = info[1] feature pairs (num_pairs, or every candidate for DENSE); rows of
  * `selected` / `s_uv` / `feat` from n_feature_rows on, and rows of `L` from 2 * n_feature_rows on, are returned as
  * -1 / 0 / 0 / 0 whatever an earlier, larger call left in the workspace.
- * Any pointer may be NULL. */
+ * Any pointer may be NULL.  After a host-pointer velocity call (vitvs_compute_velocity, vitvs_reselect) everything but
+ * `selected` and `L` is served from host memory (the handle's pinned block) without a device call. */
 VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t* nn_2, float* sim_1, int32_t* info,
                        int32_t* selected, int32_t* s_uv, double* feat, double* L);
 
@@ -232,6 +251,7 @@ VITVS_API int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1
  *                          long-sequence attention whole query blocks (no key ranges to merge), the many-row layers
  *                          256 x 256 tiles wherever they divide (fewest operand bytes per FLOP instead of launch balance)
  *                          and at most two K slices.
+ *   "reuse_goal_frames" 0 / 1  host-pointer calls: see vitvs_compute_velocity above.
  * Returns 0, or -5 for an unknown name / a value out of range. */
 VITVS_API int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value);
 /* The handles of such an arrangement run ONE network: `h` (created with the same network, input geometry and precision, no

@@ -53,6 +53,9 @@ VITVS_API int vitvs_op_attention_q(int32_t precision, const void* qkv, void* out
  *   x[M][D] (fp32) += ls[D] * (sum_z part[z] + bias)  (slices summed in index order); then, if gamma != NULL,
  *   out[M][D] = LayerNorm(x) * gamma + beta in `precision` (out may be NULL when gamma is NULL). */
 VITVS_API int vitvs_op_splitk_slices(int32_t precision, int32_t M, int32_t N, int32_t K);
+/* Measurement hook (tools/l2_warm_probe.py): the private L2 of every XCD reads all `bytes` of p (share_xcds != 0: XCD x only the
+ * x-th eighth), so that a following launch finds the operand in L2 rather than in the Infinity Cache.  No result. */
+VITVS_API int vitvs_op_touch(const void* p, int64_t bytes, int32_t share_xcds, void* stream);
 /* VITVS_F16X2 operands of the hooks: A / qkv rows and W rows hold 2 C fp16 per C logical columns, [hi of 32 columns | lo of the
  * same 32] per 64 fp16 (csrc/common.h), outputs likewise; W may carry a power of two 2^e (e = 0 .. 31, what the handle's weight
  * upload does so that the lo halves are normal fp16 numbers): this sets e for the calling thread's later vitvs_op_linear* calls

@@ -261,3 +261,56 @@ def test_attention_peaky_logits(lib):
     assert lib.vitvs_op_attention(X2, _p(qd), _p(out), n_img, N, H, _stream()) == 0
     torch.cuda.synchronize()
     assert _rel(from_x2(out.cpu()), ref) <= 2e-5
+
+
+
+@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1256, 1])
+@pytest.mark.parametrize("M,N,K,gelu", [(6274, 2304, 768, 0), (2740, 1024, 1024, 1), (1025, 256, 64, 0), (3152, 3072, 768, 1), (300, 512, 192, 0)])
+def test_linear_tile_families(lib, variant, M, N, K, gelu):
+    """The 256- / 192-row tiles of gemm_big.hip on hi / lo operands (three MFMAs per quadrant k-step, the [hi | lo] epilogue image,
+    weights carrying 2^e) and the tiles of gemm.hip on the same shapes: ragged last row tile, the shortest k-loop the big kernel
+    takes (K = 64: four k-tiles of 32 logical k ... the kernel's two-tile minimum is K = 64), a row count below one tile."""
+    if variant >= 128 and N % {1192: 128, 1256: 256}.get(variant, variant) != 0:
+        pytest.skip("this tile width does not divide N")
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = _mk((M, K), g)
+    W = _mk((N, K), g, K ** -0.5)
+    bias = _mk((N,), g, 0.1)
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    e = weight_exp(W)
+    Ad, Wd, bd = to_x2(A).cuda(), to_x2(W, e).cuda(), bias.cuda()
+    out = torch.full((M + 3, 2 * N), float("nan"), dtype=torch.float16, device="cuda")      # 3 guard rows behind the matrix
+    lib.vitvs_op_weight_exponent(e)
+    rc = lib.vitvs_op_linear_variant(X2, variant, _p(Ad), _p(Wd), _p(bd), _p(out), M, N, K, gelu, 0, _stream())
+    lib.vitvs_op_weight_exponent(0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all(), "rows beyond M were written"
+    got = from_x2(out[:M].cpu())
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("variant", [256, 192, 128, 1192, 1256, 1])
+@pytest.mark.parametrize("M,N,K,slices", [(6274, 768, 3072, 3), (2740, 1024, 1024, 2), (1500, 256, 768, 1), (1500, 384, 768, 2)])
+def test_linear_partial_tile_families(lib, variant, M, N, K, slices):
+    """Split-K partial sums from both tile families: slice z holds exactly the products of its K range (fp32-class)."""
+    if variant >= 128 and N % {1192: 128, 1256: 256}.get(variant, variant) != 0:
+        pytest.skip("this tile width does not divide N")
+    g = torch.Generator().manual_seed(M + N + K + slices)
+    A = _mk((M, K), g)
+    W = _mk((N, K), g, K ** -0.5)
+    e = weight_exp(W)
+    Ad, Wd = to_x2(A).cuda(), to_x2(W, e).cuda()
+    part = torch.full((slices, M, N), float("nan"), dtype=torch.float32, device="cuda")
+    lib.vitvs_op_weight_exponent(e)
+    rc = lib.vitvs_op_linear_variant(X2, variant, _p(Ad), _p(Wd), None, _p(part), M, N, K, 0, slices, _stream())
+    lib.vitvs_op_weight_exponent(0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ks = K // slices
+    for z in range(slices):
+        ref = A[:, z * ks:(z + 1) * ks].double() @ W[:, z * ks:(z + 1) * ks].double().t()
+        assert _rel(part[z].cpu(), ref) <= TOL

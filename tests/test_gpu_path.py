@@ -567,7 +567,12 @@ def test_compute_velocity_fp32_many_tokens(key, exact):
     S = sr.cosine_matrix(toks[0], toks[1], exact_order=False).numpy()
     a1 = _tie_tolerant_agreement(det["nn_1"][0], case["nn_1"], S, 2e-5)
     a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, 2e-5)
-    assert a1 >= 0.99 and a2 >= 0.99
+    # north_star: bit-exact arg-max.  Measured 1.0000 / 1.0000 on both configurations, in fp32 and in f16x2, on every box of rounds
+    # 3-5 (top-1 / top-2 margins here are ~1e-6, so the tie check above stays as the diagnosis: a failure names the tokens)
+    bad1 = np.nonzero(det["nn_1"][0] != case["nn_1"])[0]
+    bad2 = np.nonzero(det["nn_2"][0] != case["nn_2"])[0]
+    assert a1 == 1.0 and a2 == 1.0, (f"arg-max tables differ from the reference's at nn_1 tokens {bad1.tolist()} (oracle gaps "
+                                     f"{[float(S[i, case['nn_1'][i]] - S[i, det['nn_1'][0][i]]) for i in bad1]}) and nn_2 tokens {bad2.tolist()}")
     assert st == 0
     # v_c depends on nn_1 at the selected tokens only.  Where the device's arg-max at a selected token is the other
     # side of a <= 2e-5 tie (asserted above for every token), the oracle's law is evaluated on the device's own match
@@ -680,7 +685,8 @@ def test_16bit_modes_over_8_accepted_pairs(precision, plan):
 
 # The reference's SHIPPED configuration (config.yaml:1-17: DINOv2 ViT-S/14 at 308², use_feature_binning: true -> 9 x 384 = 3456-wide
 # descriptors, vitvs_v2.py:482-493, dinov2_extractor.py:265-311) in the 16-bit modes, under every tile plan.  Bars as measured.
-BINNED16 = {"bf16": dict(tie=2e-2, agree=0.97), "fp16": dict(tie=3e-3, agree=0.995)}
+# (agreement: measured 1.0000 on every plan in both modes; the floor leaves ONE of the 484 tokens)
+BINNED16 = {"bf16": dict(tie=2e-2, agree=483 / 484), "fp16": dict(tie=3e-3, agree=483 / 484)}
 
 
 @pytest.mark.parametrize("plan", PLANS)
@@ -698,7 +704,7 @@ def test_16bit_binned_reference_default_config(precision, plan):
     a1 = _tie_tolerant_agreement(det["nn_1"][0], case["nn_1"], S, bars["tie"])
     a2 = _tie_tolerant_agreement(det["nn_2"][0], case["nn_2"], S.T, bars["tie"])
     print(f"{key} binned {precision} [{plan}]: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f}")
-    assert st == 0 and a1 >= bars["agree"] and a2 >= bars["agree"]
+    assert st == 0 and a1 >= bars["agree"] - 1e-9 and a2 >= bars["agree"] - 1e-9
     np.testing.assert_allclose(det["sim_1"][0], case["sim_1"], rtol=0, atol=bars["tie"])
     sel = _ids(case["points1"], cfg.grid)
     dev_matches = det["nn_1"][0].astype(np.int64)[sel]
@@ -916,7 +922,10 @@ def test_trained_like_statistics_end_to_end(key, precision, plan):
 # 448², 3136 tokens), END TO END in their own dtype: these are the sizes where the 16-bit modes take the Gram on the f16
 # matrix cores from a hi / lo split of the descriptors (correspond.hip), the 256-row GEMM tiles and the key-split attention.
 # measured: fp16 ViT-L/14 518: nn_1 0.9993 / nn_2 1.0000, max |S_device - S_oracle| 1.9e-4; bf16 ViT-B/8 448: 0.9930 / 0.9936, 1.4e-3
-FULL16 = {("vitl14_518", "fp16"): dict(tie=1e-3, agree=0.995), ("vitb8_448", "bf16"): dict(tie=5e-3, agree=0.985)}
+# floors = the measured agreement minus ONE token (rounds 4-5, all three plans): fp16 ViT-L/14 1.0000 / 1.0000 of 1369 tokens;
+# bf16 ViT-B/8 nn_1 0.9901 ... 0.9917, nn_2 0.9959 ... 0.9962 of 3136 tokens
+FULL16 = {("vitl14_518", "fp16"): dict(tie=1e-3, agree1=1368 / 1369, agree2=1368 / 1369),
+          ("vitb8_448", "bf16"): dict(tie=5e-3, agree1=0.9901 - 1 / 3136, agree2=0.9959 - 1 / 3136)}
 
 
 @pytest.mark.parametrize("plan", PLANS)
@@ -958,7 +967,7 @@ def test_compute_velocity_16bit_many_tokens_full_size(key, precision, plan):
     eng.close()
     print(f"{key} {precision} [{plan}]: arg-max agreement with the fp32 oracle nn_1 {a1:.4f} nn_2 {a2:.4f} (every disagreement a tie "
           f"<= {bars['tie']}); max |S_device - S_oracle| = {desc_err:.3e}")
-    assert a1 >= bars["agree"] and a2 >= bars["agree"] and desc_err <= bars["tie"]
+    assert a1 >= bars["agree1"] - 1e-9 and a2 >= bars["agree2"] - 1e-9 and desc_err <= bars["tie"]
     # (c) the draw and the law
     want_sel = _first_mutual_in_order(order, d1, d2, k)
     assert len(want_sel) == k and np.array_equal(det["selected"][0, :k].astype(np.int64), want_sel)

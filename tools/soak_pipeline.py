@@ -31,10 +31,17 @@ def main():
     P = 40                                              # period of the (pair, order) schedule: coprime with the depth
     orders = torch.stack([torch.randperm(cfg.tokens, generator=gen) for _ in range(P)]).to(torch.int32).to(dev)[:, None]
     pipe = UpdatePipeline(cfg, params, sd, precision="bf16", depth=3)
-    free0 = torch.cuda.mem_get_info(dev)[0]
+    free0, reserved0 = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_reserved(dev)
+    free_warm = reserved_warm = None
     first, bad, tickets = {}, 0, []
     t0 = time.perf_counter()
     for i in range(n):
+        if i == 3 * P:
+            # every (slot, frame pair) has captured and instantiated its graph (24 of them: a hipGraphExec owns its kernel-argument
+            # and node memory on the device) and torch's caching allocator has created its pools (the results' .clone(): one 2 MiB
+            # small-block segment; any allocation over 1 MiB reserves a 20 MiB segment): what is in use from here on must not grow
+            torch.cuda.synchronize(dev)
+            free_warm, reserved_warm = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_reserved(dev)
         tickets.append((i, pipe.submit(cur[i % 8], des[i % 8], Z, K, _lib.SELECT_ORDER, orders[i % P])))
         if len(tickets) == 3:
             j, t = tickets.pop(0)
@@ -45,11 +52,19 @@ def main():
         v = pipe.result(t)[0].cpu().numpy().tobytes()
         bad += first.setdefault(j % P, v) != v
     dt = time.perf_counter() - t0
-    free1 = torch.cuda.mem_get_info(dev)[0]
+    torch.cuda.synchronize(dev)
+    free1, reserved1 = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_reserved(dev)
+    mib = 2.0 ** 20
+    steady = "n/a (run shorter than the warm-up)" if free_warm is None else \
+        f"{(free_warm - free1) / mib:+.1f} MiB over the {n - 3 * P} updates after it (torch's allocator {(reserved1 - reserved_warm) / mib:+.1f} MiB)"
+    warm = "" if free_warm is None else \
+        f"{(free0 - free_warm) / mib:+.1f} MiB during the first {3 * P} updates (graph capture + instantiation of 24 (slot, pair) graphs, " \
+        f"of which torch's caching allocator reserved {(reserved_warm - reserved0) / mib:+.1f} MiB), "
     print(f"{key}{' binned' if binned else ''}: {n} updates through 3 slots in {dt:.2f} s ({n / dt:.0f} updates/s with a host read per update), "
           f"{len(first)} distinct (pair, order) cases, results differing from their first pass: {bad}, "
-          f"device memory in use changed by {(free0 - free1) / 2**20:.1f} MiB")
-    sys.exit(1 if bad else 0)
+          f"device memory in use: {warm}{steady}")
+    leak = free_warm is not None and (free_warm - free1) > 2 * mib
+    sys.exit(1 if bad or leak else 0)
 
 
 if __name__ == "__main__":

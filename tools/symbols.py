@@ -5,6 +5,8 @@ _EPI = r"(EpiStore|EpiPartial|EpiPatch|EpiResidual|BigStore|BigPartial)"
 
 
 def _prec(name):
+    if "3hx2" in name or "hx2" in name:               # split-f16 operands (csrc/common.h): struct vitvs::hx2
+        return "hx2"
     if "DF16b" in name or "__bf16" in name:
         return "bf16"
     if "DF16_" in name or "_Float16" in name:

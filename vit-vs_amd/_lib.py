@@ -47,6 +47,7 @@ PROTOTYPES = {
     "vitvs_weights_ready": (_I, [_P]),
     "vitvs_compute_velocity_dev": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "vitvs_compute_velocity": (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
+    "vitvs_reselect": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "vitvs_set_goal_dev": (_I, [_P, _I, _P, _P]),
     "vitvs_set_goal": (_I, [_P, _I, _P]),
     "vitvs_extract_descriptors_dev": (_I, [_P, _I, _P, _P, _P]),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     "vitvs_op_splitk_slices": (_I, [_I, _I, _I, _I]),
     "vitvs_op_plan_in_flight": (_I, [_I]),
     "vitvs_op_weight_exponent": (_I, [_I]),
+    "vitvs_op_touch": (_I, [_P, C.c_int64, _I, _P]),
     "vitvs_op_linear_tile": (_I, [_I, _I, _I, _I, _I, _P]),
     "vitvs_op_linear_partial": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vitvs_op_residual_ln": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),

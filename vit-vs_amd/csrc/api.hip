@@ -150,12 +150,31 @@ struct vitvs_handle {
         unsigned char* det = nullptr;   // image of the device's detail block (info | s_uv | feat) of the last host-pointer call
     } hs;
     hipStream_t host_stream = nullptr;
-    bool details_pinned = false;        // hs.det holds the last call's info / s_uv / feat (vitvs_last_details serves them from there)
-    unsigned char* det_block = nullptr; // device: info [P][8] i32 | s_uv [P][R][4] i32 | feat [P][R][4] f64, one allocation
+    bool details_pinned = false;        // hs.det holds the last call's detail block (vitvs_last_details serves it from there)
+    struct HostTables { int n_pairs = 0, T = 0; bool have_depth = false; } host_tables;   // what vitvs_reselect may build on
+    unsigned char* det_block = nullptr; // device copy of the detail block (detail_pointers), one allocation
     size_t det_bytes = 0;
+    bool reuse_goal = false;            // option "reuse_goal_frames": I_des of a host-pointer call is not staged again while its address repeats
+    const void* staged_des = nullptr;   // host address, frame count and geometry of the goal frames in st_des
+    size_t staged_des_bytes = 0;
 };
 
 namespace {
+
+// The detail block — what vitvs_last_details hands out except `selected` and L — is one allocation laid out
+// info [P][8] i32 | s_uv [P][R][4] i32 | feat [P][R][4] f64 | nn_1 [P][T] i32 | nn_2 [P][T] i32 | sim_1 [P][T] f32.  The law's kernel
+// writes it in device memory, or — host-pointer calls — straight into the handle's pinned block (same layout), so that the
+// reference's return values (s_uv*, s_uv, the selected similarities, and the tables its host-side draw needs) reach the host with
+// the twist, without a copy launch or a device-to-host copy.
+void detail_pointers(vitvs_handle* h, unsigned char* base) {
+    const size_t P = h->cfg.max_pairs, R = h->cfg.max_rows;
+    h->info = reinterpret_cast<int32_t*>(base);
+    h->s_uv = reinterpret_cast<int32_t*>(base + P * 32);
+    h->feat = reinterpret_cast<double*>(base + P * 32 + P * R * 16);
+    h->nn1 = reinterpret_cast<int32_t*>(base + P * 32 + P * R * 48);
+    h->nn2 = h->nn1 + h->best_elems;
+    h->sim1 = reinterpret_cast<float*>(h->nn2 + h->best_elems);
+}
 
 int set_err(vitvs_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -493,6 +512,7 @@ int ensure_host_stage(vitvs_handle* h) {
         (void)hipHostFree(h->hs.base);
         h->hs = vitvs_handle::HostStage{};
         h->details_pinned = false;
+        h->staged_des = nullptr;
     }
     const size_t P = c.max_pairs, fb = (h->staged_frame_bytes + 255) & ~(size_t)255;
     const size_t sel_cap = P * (size_t)(h->T > c.max_rows ? h->T : c.max_rows);
@@ -610,17 +630,10 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->best_elems = (size_t)cfg->max_pairs * h->T;
     if (!rc) rc = dev_alloc(h, &h->row_best, h->best_elems);
     if (!rc) rc = dev_alloc(h, &h->col_best, h->best_elems);
-    if (!rc) rc = dev_alloc(h, &h->nn1, h->best_elems);
-    if (!rc) rc = dev_alloc(h, &h->nn2, h->best_elems);
-    if (!rc) rc = dev_alloc(h, &h->sim1, h->best_elems);
     const size_t P = cfg->max_pairs, R = cfg->max_rows;
-    h->det_bytes = P * 32 + P * R * 16 + P * R * 32;
+    h->det_bytes = P * 32 + P * R * 16 + P * R * 32 + 3 * h->best_elems * 4;
     if (!rc) rc = dev_alloc(h, &h->det_block, h->det_bytes);
-    if (!rc) {
-        h->info = reinterpret_cast<int32_t*>(h->det_block);
-        h->s_uv = reinterpret_cast<int32_t*>(h->det_block + P * 32);
-        h->feat = reinterpret_cast<double*>(h->det_block + P * 32 + P * R * 16);
-    }
+    if (!rc) detail_pointers(h, h->det_block);
     if (!rc) rc = dev_alloc(h, &h->sel_out, P * R);
     if (!rc) rc = dev_alloc(h, &h->Lws, P * 7 * 2 * R);
     const size_t img_bytes = (size_t)cfg->img_size * cfg->img_size * 3;
@@ -864,6 +877,7 @@ int vitvs_set_frame_size(vitvs_handle* h, int32_t in_h, int32_t in_w) {
     drop_graphs(h);
     (void)resize_tables(h, h->fr, 0, 0);            // frees the previous tables
     h->fr = fresh;
+    h->staged_des = nullptr;                        // frames of another geometry
     if (new_cur) {
         dev_free(h, h->st_cur);
         dev_free(h, h->st_des);
@@ -1046,7 +1060,8 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
     const std::vector<uintptr_t> key = {(uintptr_t)u.n_pairs, (uintptr_t)u.I_cur, (uintptr_t)u.I_des, (uintptr_t)u.des_shared,
                                         (uintptr_t)u.Z_mm, (uintptr_t)u.K, (uintptr_t)u.select_mode, (uintptr_t)u.num_pairs,
                                         (uintptr_t)(u.selection != nullptr), (uintptr_t)(u.n_selected != nullptr),
-                                        (uintptr_t)u.v_c, (uintptr_t)u.status, (uintptr_t)h->fr.in_h, (uintptr_t)h->fr.in_w};
+                                        (uintptr_t)u.v_c, (uintptr_t)u.status, (uintptr_t)h->fr.in_h, (uintptr_t)h->fr.in_w,
+                                        (uintptr_t)h->info};          // (the detail block the law writes: device or pinned)
     vitvs_handle::GraphEntry* ge = nullptr;
     for (auto& g : h->graphs)
         if (g.key == key) ge = &g;
@@ -1106,6 +1121,7 @@ int vitvs_set_goal(vitvs_handle* h, int32_t n_goal, const uint8_t* I_des) {
     if (int rc = ensure_host_stage(h)) return rc;
     const size_t img = frame_bytes(h);
     memcpy(h->hs.des, I_des, n_goal * img);
+    h->staged_des = nullptr;
     int rc = launch_copy16(h->hs.des, h->st_des, n_goal * img, h->host_stream);
     if (rc) return set_err(h, rc, "frame staging launch failed");
     rc = vitvs_set_goal_dev(h, n_goal, h->st_des, h->host_stream);
@@ -1128,6 +1144,7 @@ static int velocity_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
         return set_err(h, -5, "I_des is NULL and no goal of this shape is cached (vitvs_set_goal_dev)");
     if (u.I_des) h->goal_frames = 0;            // the call forwards goal frames of its own over the cached rows
     h->details_pinned = false;                  // the detail block on the device is about to change
+    h->host_tables = vitvs_handle::HostTables{};
     if (h->use_graphs && !h->timing && st != nullptr) return replay_update(h, u, st);
     return enqueue_update(h, u, st);
 }
@@ -1165,9 +1182,14 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     const size_t img = frame_bytes(h), n_des = des_shared ? 1 : n_pairs;
     memcpy(hs.cur, I_cur, n_pairs * img);
     int rc = launch_copy16(hs.cur, h->st_cur, n_pairs * img, st);
-    if (!rc && I_des) {
+    // option "reuse_goal_frames": a control loop's goal image does not change — while the caller passes the same address (and
+    // count, and geometry) the goal frames staged by the previous call are still in device memory and are forwarded again as they are
+    const bool goal_staged = h->reuse_goal && I_des && I_des == h->staged_des && n_des * img == h->staged_des_bytes;
+    if (!rc && I_des && !goal_staged) {
         memcpy(hs.des, I_des, n_des * img);
         rc = launch_copy16(hs.des, h->st_des, n_des * img, st);
+        h->staged_des = I_des;
+        h->staged_des_bytes = n_des * img;
     }
     if (rc) return set_err(h, rc, "frame staging launch failed");
     memcpy(hs.K, K, (size_t)n_pairs * 4 * sizeof(double));
@@ -1180,14 +1202,49 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     UpdateArgs u{n_pairs, des_shared, select_mode, np, h->st_cur, I_des ? h->st_des : nullptr, Z_mm ? hs.depth : nullptr, hs.K,
                  hs.sel, hs.nsel, hs.vc, hs.status};
     if (Z_mm) { u.late_src = Z_mm; u.late_dst = hs.depth; u.late_bytes = (size_t)n_pairs * c.u_max * c.v_max * 2; }
+    detail_pointers(h, hs.det);                  // the law writes this call's details into the pinned block
     rc = velocity_update(h, u, st);
+    detail_pointers(h, h->det_block);
     if (rc) return rc;
-    rc = launch_copy16(h->det_block, hs.det, h->det_bytes, st);      // info | s_uv | feat of this call: vitvs_last_details
-    if (rc) return set_err(h, rc, "detail copy launch failed");
     if (int w = wait_stream(st)) return w;
     memcpy(v_c, hs.vc, (size_t)n_pairs * 6 * sizeof(double));
     memcpy(status, hs.status, (size_t)n_pairs * 4);
     h->details_pinned = true;
+    h->host_tables = vitvs_handle::HostTables{n_pairs, h->T, Z_mm != nullptr};
+    return 0;
+}
+
+// The reference draws its feature tokens on the HOST, between the correspondence and the law (find_correspondences_batch:
+// sort + torch.randperm, vitvs_v2.py:127-141): a host-pointer call gives the tables (vitvs_last_details serves nn_1 / nn_2 /
+// sim_1 of a host-pointer call from host memory), the caller draws, and this entry point runs the law again for that draw on
+// what the call left in the handle — the arg-max keys on the device, the depth image and intrinsics in the pinned block: one
+// short launch, no forward, no staging.
+int vitvs_reselect(vitvs_handle* h, int32_t select_mode, const int32_t* selection, const int32_t* n_selected, int32_t num_pairs,
+                   double* v_c, int32_t* status) {
+    if (!h || !v_c || !status) return set_err(h, -1, "null argument");
+    if (!h->details_pinned || h->host_tables.n_pairs <= 0 || !h->hs.base)
+        return set_err(h, -5, "vitvs_reselect follows a host-pointer velocity call on the same handle (vitvs_compute_velocity)");
+    const int n_pairs = h->host_tables.n_pairs, T = h->host_tables.T;
+    const int np = call_num_pairs(h, num_pairs);
+    if (np > h->cfg.max_rows) return set_err(h, -5, "num_pairs exceeds max_rows");
+    if (select_mode == VITVS_SELECT_EXPLICIT && (!selection || !n_selected)) return set_err(h, -5, "EXPLICIT selection needs ids and counts");
+    if (select_mode == VITVS_SELECT_ORDER && !selection) return set_err(h, -5, "ORDER selection needs a visiting order");
+    DeviceScope dev(h);
+    vitvs_handle::HostStage& hs = h->hs;
+    if (select_mode == VITVS_SELECT_EXPLICIT) {
+        memcpy(hs.sel, selection, (size_t)n_pairs * np * 4);
+        memcpy(hs.nsel, n_selected, (size_t)n_pairs * 4);
+    } else if (select_mode == VITVS_SELECT_ORDER) {
+        memcpy(hs.sel, selection, (size_t)n_pairs * T * 4);
+    }
+    detail_pointers(h, hs.det);
+    const int rc = run_servo(h, n_pairs, T, h->host_tables.have_depth ? hs.depth : nullptr, hs.K, select_mode, np, hs.sel, hs.nsel, hs.vc,
+                             hs.status, h->host_stream);
+    detail_pointers(h, h->det_block);
+    if (rc) return rc;
+    if (int w = wait_stream(h->host_stream)) return w;
+    memcpy(v_c, hs.vc, (size_t)n_pairs * 6 * sizeof(double));
+    memcpy(status, hs.status, (size_t)n_pairs * 4);
     return 0;
 }
 
@@ -1201,10 +1258,20 @@ int vitvs_last_details(vitvs_handle* h, int32_t n_pairs, int32_t* nn_1, int32_t*
     // for those alone (the reference's detect_features return value: s_uv*, s_uv, the selected similarities) costs no HIP call
     const bool pinned = h->details_pinned;
     const unsigned char* pd = h->hs.det;
-    if (!pinned || nn_1 || nn_2 || sim_1 || selected || L) VITVS_HIP_CHECK(hipDeviceSynchronize());
-    if (nn_1) VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
-    if (nn_2) VITVS_HIP_CHECK(hipMemcpy(nn_2, h->nn2, P * T * 4, hipMemcpyDeviceToHost));
-    if (sim_1) VITVS_HIP_CHECK(hipMemcpy(sim_1, h->sim1, P * T * 4, hipMemcpyDeviceToHost));
+    if (!pinned || selected || L) VITVS_HIP_CHECK(hipDeviceSynchronize());
+    const size_t o_nn = PM * 32 + PM * R * 48;              // nn_1 | nn_2 | sim_1 behind info | s_uv | feat (detail_pointers)
+    if (nn_1) {
+        if (pinned) memcpy(nn_1, pd + o_nn, P * T * 4);
+        else VITVS_HIP_CHECK(hipMemcpy(nn_1, h->nn1, P * T * 4, hipMemcpyDeviceToHost));
+    }
+    if (nn_2) {
+        if (pinned) memcpy(nn_2, pd + o_nn + h->best_elems * 4, P * T * 4);
+        else VITVS_HIP_CHECK(hipMemcpy(nn_2, h->nn2, P * T * 4, hipMemcpyDeviceToHost));
+    }
+    if (sim_1) {
+        if (pinned) memcpy(sim_1, pd + o_nn + 2 * h->best_elems * 4, P * T * 4);
+        else VITVS_HIP_CHECK(hipMemcpy(sim_1, h->sim1, P * T * 4, hipMemcpyDeviceToHost));
+    }
     std::vector<int32_t> inf(P * 8);
     if (pinned) memcpy(inf.data(), pd, P * 8 * 4);
     else VITVS_HIP_CHECK(hipMemcpy(inf.data(), h->info, P * 8 * 4, hipMemcpyDeviceToHost));
@@ -1240,6 +1307,12 @@ int vitvs_set_option(vitvs_handle* h, const char* name, int64_t value) {
     if (nm == "graph_replay") {
         if (value != 0 && value != 1) return set_err(h, -5, "graph_replay takes 0 or 1");
         h->use_graphs = value == 1;
+        return 0;
+    }
+    if (nm == "reuse_goal_frames") {
+        if (value != 0 && value != 1) return set_err(h, -5, "reuse_goal_frames takes 0 or 1");
+        h->reuse_goal = value == 1;
+        h->staged_des = nullptr;
         return 0;
     }
     if (nm == "in_flight") {
@@ -1307,12 +1380,12 @@ int vitvs_op_linear_variant(int32_t precision, int32_t variant, const void* A, c
     if (variant == 1)
         return slices > 0 ? launch_linear_partial_classic(p, A, W, (float*)out, M, N, K, slices, st, g_op_wexp)
                           : launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, st, g_op_wexp);
-    if (p == PREC_X2) return -2;                   // the tile families below are 16-bit only
-    if (variant == 2) return launch_linear_128(p, A, W, bias, out, M, N, K, gelu, slices > 0 ? slices : 1, slices > 0, st);
-    if (variant == 1256) return (N % 256 || K % 64) ? -2 : launch_linear_big(p, 1256, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
-    if (variant == 1192) return (N % 128 || K % 64) ? -2 : launch_linear_big(p, 1192, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
-    if ((variant != 256 && variant != 192 && variant != 128) || N % variant != 0 || K % 64 != 0) return -2;
-    return launch_linear_big(p, variant, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st);
+    if (variant == 2) return p == PREC_X2 ? -2 : launch_linear_128(p, A, W, bias, out, M, N, K, gelu, slices > 0 ? slices : 1, slices > 0, st);
+    const int kk = (p == PREC_X2 ? 2 : 1) * K;     // elements per row of the big kernels' operands
+    if (variant == 1256) return (N % 256 || kk % 64) ? -2 : launch_linear_big(p, 1256, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st, g_op_wexp);
+    if (variant == 1192) return (N % 128 || kk % 64) ? -2 : launch_linear_big(p, 1192, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st, g_op_wexp);
+    if ((variant != 256 && variant != 192 && variant != 128) || N % variant != 0 || kk % 64 != 0) return -2;
+    return launch_linear_big(p, variant, A, W, bias, out, M, N, K, slices > 0 ? slices : 1, gelu, slices > 0, st, g_op_wexp);
 }
 int vitvs_op_linear_residual(int32_t precision, const void* A, const void* W, const float* bias, const float* ls,
                              float* x, int32_t M, int32_t N, int32_t K, void* stream) {
@@ -1341,6 +1414,10 @@ int vitvs_op_linear_tile(int32_t precision, int32_t M, int32_t N, int32_t K, int
     const int rc = linear_tile_plan(to_prec(precision), M, N, K, slices > 0 ? slices : 1, slices > 0, t);
     tile[0] = t[0]; tile[1] = t[1]; tile[2] = t[2];
     return rc;
+}
+int vitvs_op_touch(const void* p, int64_t bytes, int32_t share_xcds, void* stream) {
+    DeviceScope dev(nullptr);
+    return launch_touch(p, (size_t)bytes, share_xcds, as_stream(stream));
 }
 int vitvs_op_plan_in_flight(int32_t n) {
     const int prev = g_updates_in_flight;

@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "probe.h"
 
 namespace vitvs {
 
@@ -242,11 +243,16 @@ __global__ __launch_bounds__(256 * KS) void attention_16_kernel(const HT* __rest
 // is bound by vector issue, not by the matrix pipe (profiles/r02_notes.md has the variants that did not move it:
 // 16x16x32 tiles, staggered workgroup starts, fewer address instructions).
 #ifdef VITVS_PROBE
-// probe builds only (tools/big_ops probe): per-wave cycle sums of the tile loop's parts + realtime span
+// probe builds only (tools/big_ops probe): per-wave cycle sums of the tile loop's parts + realtime span (probe.h)
 __device__ unsigned long long* g_attn_probe;
-#define VITVS_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define VITVS_STAMP(var) do { } while (0)
+static int g_attn_lds_bytes = 3 * 2 * 64 * 128;   // dynamic LDS per workgroup of the long kernel: limits how many share a CU (48 KB: 3, 64 KB: 2, 100 KB: 1)
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_lds(int bytes) {
+    g_attn_lds_bytes = bytes < 3 * 2 * 64 * 128 ? 3 * 2 * 64 * 128 : bytes;
+    return 0;
+}
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -283,7 +289,11 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __
 // starts inside an item (its first), slot 1 = the one that starts an item and ends inside it (its last).
 constexpr int kAttnStateFloats = 9 * 64 * 4;                // per wave: 8 x 16 bytes of accumulators + (maximum, sum), lane-major
 
-template <typename HT>
+// ONES (measured variant; launch_attention_16 has the outcome): the row sums l = sum_k P come out of the matrix
+// pipe — a third 32-row block of V^T whose rows are all ones, i.e. one more MFMA per 16-key step with a constant A operand —
+// instead of 32 vector adds per tile; the fast path's headroom test then takes the maximum of the shifted scores (16 v_max3)
+// BEFORE the exponentials rather than the sum of the probabilities after them.
+template <typename HT, bool ONES = false>
 __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
                                                                    int D, int n_img, int per, int g_per_xcd, float qscale,
                                                                    float* __restrict__ ws, int* __restrict__ tickets) {
@@ -315,10 +325,10 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
     const int v_sw = ((v_row >> 1) & 1) << 1;                    // window swizzle of that row (the 8-row step keeps bit 1)
     int* flag = reinterpret_cast<int*>(smem + 3 * STAGE);        // one word behind the ring (same LDS array)
     int slot = 0;                                                 // ring slot of the NEXT tile to be computed; runs on across segments
-#ifdef VITVS_PROBE
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0}, tiles_done = 0, segs = 0, xchg = 0, tx0 = 0, tx1 = 0, slow_tiles = 0;
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
-#endif
+    VITVS_IF_PROBE(
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, sum[5] = {0, 0, 0, 0, 0}, tiles_done = 0, segs = 0, xchg = 0, tx0 = 0, tx1 = 0, slow_tiles = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
+    )
     while (w0 < w1) {
     const int item = w0 / nt, t_begin = w0 - item * nt, ntiles = min(nt - t_begin, w1 - w0);
     w0 += ntiles;
@@ -402,6 +412,12 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
     float l_run = 0.f;
+    f32x16 acc_l;                                                // ONES: every row = the query's running sum of P (over ALL keys)
+    hx8 ones;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_l[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (HT)1.f;
     for (int t = 0; t < ntiles; ++t) {
         VITVS_STAMP(ts0);
         if (t + 1 < ntiles) wait_vmcnt4();
@@ -435,9 +451,7 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
             }
         };
         scores(true);
-#ifdef VITVS_PROBE
-        asm volatile("s_nop 0" ::"v"(acc_s[0][0]), "v"(acc_s[1][15]) : "memory");
-#endif
+        VITVS_IF_PROBE(asm volatile("s_nop 0" ::"v"(acc_s[0][0]), "v"(acc_s[1][15]) : "memory");)
         VITVS_STAMP(ts3);
         // V fragments (hardware-transposed reads), requested now and consumed after the softmax.  Inline asm: for the
         // ds_read_tr16 builtin hipcc waits vmcnt(0) first (it cannot tell the LDS-DMA copies in flight apart from the
@@ -474,20 +488,37 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
         float psum = 0.f;
         if (!slow) {
             mask_tail();
+            if constexpr (ONES) {
+                // every p = exp2(s - m_t) stays <= 64 iff the largest shifted score is <= 6: tested before the exponentials
+                float mx = max3(acc_s[0][0], acc_s[0][1], acc_s[0][2]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int i = 3; i < 15; i += 2) mx = max3(mx, acc_s[0][i], acc_s[0][i + 1]);
+                mx = max3(mx, acc_s[0][15], acc_s[1][0]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = fast_exp2(acc_s[kb][i]);
-                    acc_s[kb][i] = p;
-                    psum += p;
+                for (int i = 1; i < 15; i += 2) mx = max3(mx, acc_s[1][i], acc_s[1][i + 1]);
+                mx = fmaxf(mx, acc_s[1][15]);
+                slow = __builtin_amdgcn_ballot_w64(!(mx <= 6.f)) != 0ull;        // (a NaN score also lands here)
+                if (slow) scores(false);
+                else {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc_s[kb][i] = fast_exp2(acc_s[kb][i]);
                 }
-            slow = __builtin_amdgcn_ballot_w64(!(psum <= 64.f)) != 0ull;     // (an inf or NaN sum also lands here)
-            if (slow) scores(false);                     // the accumulators hold p now: raw scores again (the K tile is still in LDS)
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = fast_exp2(acc_s[kb][i]);
+                        acc_s[kb][i] = p;
+                        psum += p;
+                    }
+                slow = __builtin_amdgcn_ballot_w64(!(psum <= 64.f)) != 0ull;     // (an inf or NaN sum also lands here)
+                if (slow) scores(false);                     // the accumulators hold p now: raw scores again (the K tile is still in LDS)
+            }
         }
-#ifdef VITVS_PROBE
-        if (slow) ++slow_tiles;
-#endif
+        VITVS_IF_PROBE(if (slow) ++slow_tiles;)
         if (slow) {
             if (t == 0 && m_t != -INFINITY) scores(false);   // (never: a segment starts with m_t = -inf, qm = 0, i.e. raw scores)
             mask_tail();
@@ -505,6 +536,10 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
             const float m_new = (float)m_hi + (float)m_lo;   // the shift the MFMAs will subtract from now on
             const float alpha = fast_exp2(m_t - m_new);  // 0 on a first tile (m_t = -inf; O = l = 0 anyway)
             l_run *= alpha;
+            if constexpr (ONES) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_l[i] *= alpha;
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -519,10 +554,10 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
                 for (int i = 0; i < 16; ++i) {
                     const float p = fast_exp2(acc_s[kb][i] - m_new);
                     acc_s[kb][i] = p;
-                    psum += p;
+                    if constexpr (!ONES) psum += p;
                 }
         }
-        l_run += psum;
+        if constexpr (!ONES) l_run += psum;
         hx8 pf[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -543,17 +578,20 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
                 const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 acc_o[db] = mfma32(__builtin_bit_cast(hx8, v8), pf[st], acc_o[db]);
             }
-#ifdef VITVS_PROBE
-        asm volatile("s_nop 0" ::"v"(acc_o[0][0]), "v"(acc_o[1][15]) : "memory");
-        VITVS_STAMP(ts5);
-        sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4;
-        ++tiles_done;
-#endif
+        if constexpr (ONES) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc_l = mfma32(ones, pf[st], acc_l);
+        }
+        VITVS_IF_PROBE(
+            asm volatile("s_nop 0" ::"v"(acc_o[0][0]), "v"(acc_o[1][15]) : "memory");
+            VITVS_STAMP(ts5);
+            sum[0] += ts1 - ts0; sum[1] += ts2 - ts1; sum[2] += ts3 - ts2; sum[3] += ts4 - ts3; sum[4] += ts5 - ts4;
+            ++tiles_done;
+        )
     }
-    l_run += lane_xor32(l_run);                                // both lane halves hold the query's whole sum
-#ifdef VITVS_PROBE
-    ++segs;
-#endif
+    if constexpr (ONES) l_run = acc_l[0];                      // (the contraction runs over the whole tile: both lane halves' keys)
+    else l_run += lane_xor32(l_run);                           // both lane halves hold the query's whole sum
+    VITVS_IF_PROBE(++segs;)
     VITVS_STAMP(tx0);
     if (ntiles != nt) {
         // a partial segment: leave its state, ws[2 g + slot][wave][group 0 .. 8][lane] x 16 bytes, written through (sc1)
@@ -577,9 +615,7 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
         __syncthreads();
         const bool last = *flag == last_g - first_g;           // workgroup-uniform
         __syncthreads();                                       // everyone has read the flag before a later segment rewrites it
-#ifdef VITVS_PROBE
-        if (!last) { VITVS_STAMP(tx1); xchg += tx1 - tx0; }
-#endif
+        VITVS_IF_PROBE(if (!last) { VITVS_STAMP(tx1); xchg += tx1 - tx0; })
         if (!last) continue;                                   // another workgroup finishes this item
         // The other segments' states are read with sc1 loads, every byte of them: written through by their producers (sc1
         // stores, drained by every storing wave before the workgroup's one ticket add), they are in memory, and an sc1 load
@@ -644,19 +680,17 @@ __global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __r
                 store_out<false>(dst + 32 * db + 8 * g4, o);
             }
     }
-#ifdef VITVS_PROBE
-    VITVS_STAMP(tx1); xchg += tx1 - tx0;
-#endif
+    VITVS_IF_PROBE(VITVS_STAMP(tx1); xchg += tx1 - tx0;)
     }   // segments
-#ifdef VITVS_PROBE
-    if (lane == 0 && g_attn_probe) {
-        unsigned long long* dst = g_attn_probe + ((size_t)blockIdx.x * 4 + wave) * 14;
-        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3]; dst[4] = sum[4];
-        dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = rt1 - rt0; dst[7] = tiles_done;
-        dst[8] = rt0; dst[9] = rt1; dst[10] = xchg; dst[11] = segs; dst[12] = slow_tiles; dst[13] = 0;
-    }
-#endif
+    VITVS_IF_PROBE(
+        if (lane == 0 && g_attn_probe) {
+            unsigned long long* dst = g_attn_probe + ((size_t)blockIdx.x * 4 + wave) * 14;
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+            dst[0] = sum[0]; dst[1] = sum[1]; dst[2] = sum[2]; dst[3] = sum[3]; dst[4] = sum[4];
+            dst[5] = __builtin_readcyclecounter() - ct0; dst[6] = rt1 - rt0; dst[7] = tiles_done;
+            dst[8] = rt0; dst[9] = rt1; dst[10] = xchg; dst[11] = segs; dst[12] = slow_tiles; dst[13] = 0;
+        }
+    )
 }
 
 // ------------------------------------------------------------------------------------ bf16, short sequences
@@ -1270,18 +1304,6 @@ __global__ __launch_bounds__(256) void attention_x2_short_kernel(const hx2* __re
     if (q < N) store_x2<true>(out + ((size_t)img * N + q) * D * 2, h * 64 + 16 * wave + 4 * g, f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv});
 }
 
-#ifdef VITVS_PROBE
-extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_probe(void* p) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-// probe builds only: dynamic LDS per workgroup of the long kernel, to limit how many share a CU (48 KB: 3, 64 KB: 2, 100 KB: 1)
-static int g_attn_lds_bytes = 3 * 2 * 64 * 128;
-extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_attn_lds(int bytes) {
-    g_attn_lds_bytes = bytes < 3 * 2 * 64 * 128 ? 3 * 2 * 64 * 128 : bytes;
-    return 0;
-}
-#endif
-
 // Work division of the long-sequence kernel: `per` key tiles per workgroup (see the kernel's header).  Measured on MI355X
 // (profiles/r03_notes.md, attention): the three workgroups a CU holds do NOT share it evenly — issue arbitration is by age, the
 // first-dispatched workgroup runs almost unimpeded — and three resident workgroups finish tiles only 1.3x faster than one, so an
@@ -1380,16 +1402,23 @@ static int launch_attention_16(const HT* qkv, HT* out, int n_img, int N, int H, 
             if (!ws || !ws->state || !ws->tickets) return -3;
         }
         int lds = 3 * 2 * 64 * 128 + 16;
-#ifdef VITVS_PROBE
-        lds = g_attn_lds_bytes + 16;
-        if (lds > 64 * 1024) {
-            static std::atomic<unsigned long long> raised{0};
-            if (raise_lds_limit((const void*)attention_16_long_kernel<HT>, 160 * 1024, raised)) return -3;
-        }
-#endif
+        VITVS_IF_PROBE(
+            lds = g_attn_lds_bytes + 16;
+            if (lds > 64 * 1024) {
+                static std::atomic<unsigned long long> raised{0};
+                if (raise_lds_limit((const void*)attention_16_long_kernel<HT, false>, 160 * 1024, raised)) return -3;
+            }
+        )
         const int g_per_xcd = (pl.groups + 7) / 8;
-        launch(attention_16_long_kernel<HT>, dim3(8 * g_per_xcd), dim3(256), lds, stream, qkv, out, N, D, n_img, pl.per, g_per_xcd, sc,
-               pl.divided ? ws->state : nullptr, pl.divided ? ws->tickets : nullptr);
+        // Row sums on the matrix pipe (the ONES variant above): VITVS_ATTN_ONES=1 selects it for A/B runs; the measured outcome is
+        // in profiles/r05_notes.md — the default is what measured faster.
+        static const bool ones_variant = [] { const char* e = getenv("VITVS_ATTN_ONES"); return e && e[0] == '1'; }();
+        if (ones_variant)
+            launch((attention_16_long_kernel<HT, true>), dim3(8 * g_per_xcd), dim3(256), lds, stream, qkv, out, N, D, n_img, pl.per, g_per_xcd, sc,
+                   pl.divided ? ws->state : nullptr, pl.divided ? ws->tickets : nullptr);
+        else
+            launch((attention_16_long_kernel<HT, false>), dim3(8 * g_per_xcd), dim3(256), lds, stream, qkv, out, N, D, n_img, pl.per, g_per_xcd, sc,
+                   pl.divided ? ws->state : nullptr, pl.divided ? ws->tickets : nullptr);
     } else if ((long)nt * H * n_img <= 256 && nt >= 2) {
         launch((attention_16_kernel<HT, 2>), grid, dim3(512), 2 * 2 * 64 * 128, stream, qkv, out, N, D, sc);
     } else {

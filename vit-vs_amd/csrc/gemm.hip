@@ -8,6 +8,7 @@
 
 #include "gemm_core.h"
 #include "kernels.h"
+#include "probe.h"
 
 namespace vitvs {
 
@@ -143,8 +144,11 @@ struct EpiPartial {
 };
 
 #ifdef VITVS_PROBE
-// probe builds only (tools/gemm_probe.cpp): per-wave cycle-counter stamps of the kernel's phases
+// probe builds only (tools/gemm_probe.cpp): per-wave cycle-counter stamps of the kernel's phases (probe.h)
 __device__ unsigned long long* g_gemm_probe;
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_gemm_probe(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 #define VITVS_EPI_WT(BM) ((BM) < 128)
@@ -156,12 +160,8 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
     // [23:19] e: f16x2 weights arrive multiplied by 2^e (api.hip upload_matrix), the sums leave multiplied by 2^-e,
     // [18] staged epilogue, [16] XCD map, [15:0] i0: one preloaded dword instead of gridDim (hidden kernel arguments the
     // wave would have to fetch) and an integer division.
-#ifdef VITVS_PROBE
-    unsigned long long ts[8];
-    ts[0] = __builtin_readcyclecounter();
-#else
-    unsigned long long* const ts = nullptr;
-#endif
+    VITVS_IF_PROBE(unsigned long long ts_buf[8]; ts_buf[0] = __builtin_readcyclecounter();)
+    unsigned long long* const ts = VITVS_PROBE_OR_NULL(ts_buf);   // per-phase stamps: null in the product build (folded away)
     using Tile = GemmTile<BM, BN, KG, NS>;
     Epi epi = Epi::make(out, c0, c1, M, N, ks_i0 & 0xffff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
 #pragma unroll
     for (int ni = 0; ni < Tile::NT; ++ni) col[ni] = epi.column_terms(min(n0 + wn * Tile::WN + ni * 16 + 4 * (lane >> 4), N - 4));
     gemm_mainloop<T, BM, BN, KG, NS>(A, W, K, K, M, N, m0, n0, tz * kslice, (tz + 1) * kslice, smem, acc, ts);
-#ifdef VITVS_PROBE
-    asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
-    ts[4] = __builtin_readcyclecounter();
-#endif
+    VITVS_IF_PROBE(
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[Tile::NT - 1][Tile::MT - 1][3]) : "memory");
+        ts[4] = __builtin_readcyclecounter();
+    )
     if constexpr (kSplit<T>) {
         const float ws = __uint_as_float((127u - ((pk >> 19) & 31u)) << 23);   // 2^-e, exact
 #pragma unroll
@@ -252,24 +252,17 @@ __global__ __launch_bounds__(256 * KG) void linear_kernel(const T* __restrict__ 
             if (m < M && n < N) epi.template store<VITVS_EPI_WT(BM)>(m, n, acc[ni][mi], col[ni]);   // 64-row tiles: one-wave launches
         }
     }
-#ifdef VITVS_PROBE
-    ts[5] = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ts[6] = __builtin_readcyclecounter();
-    if (lane == 0 && g_gemm_probe) {
-        const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        unsigned long long* dst = g_gemm_probe + ((size_t)wg * 8 + (threadIdx.x >> 6)) * 8;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) dst[i] = ts[i];
-    }
-#endif
+    VITVS_IF_PROBE(
+        ts[5] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[6] = __builtin_readcyclecounter();
+        if (lane == 0 && g_gemm_probe) {
+            const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            unsigned long long* dst = g_gemm_probe + ((size_t)wg * 8 + (threadIdx.x >> 6)) * 8;
+            for (int i = 0; i < 7; ++i) dst[i] = ts[i];
+        }
+    )
 }
-
-#ifdef VITVS_PROBE
-extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_gemm_probe(void* p) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 static int k_tile(Precision p) { return plain16(p) ? 64 : 32; }   // logical k per 128-byte k-tile (f16x2: 32, hi and lo halves)
 
@@ -420,7 +413,7 @@ static int launch_tiles64(const T* A, const T* W, int M, int N, int K, const Epi
 int launch_linear(Precision p, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int gelu, hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K)) return -2;
-    if (const int bn = big_tile_width(p, M, N, K, 1, false)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream);
+    if (const int bn = big_tile_width(p, M, N, K, 1, false)) return launch_linear_big(p, bn, A, W, bias, out, M, N, K, 1, gelu, false, stream, wexp);
     return launch_linear_classic(p, A, W, bias, out, M, N, K, gelu, stream, wexp);
 }
 
@@ -463,7 +456,7 @@ int splitk_slices(Precision p, int M, int N, int K) {
     // Many rows, narrow layer (8 frame pairs or a 518² input through proj / fc2): the 256x128 tiles of gemm_big.hip fill
     // well under half of the chip (78 tiles at 3152 x 768), so K is cut into the most slices that still fit one workgroup
     // per CU and leave >= 8 k-tiles per slice (3152 x 768 x 3072: 35 us on the tiles below -> 3 slices of 234 tiles).
-    if (plain16(p) && M >= 1024 && N % 128 == 0) {
+    if (p != PREC_F32 && M >= 1024 && N % 128 == 0) {
         const long t128 = (long)((M + 255) / 256) * (N / 128);
         if (t128 >= 96) return 1;
         int pick = 1;
@@ -495,7 +488,7 @@ int launch_linear_partial(Precision p, const void* A, const void* W, float* part
                           hipStream_t stream, int wexp) {
     if (!shapes_ok(p, M, N, K) || splits < 1 || (K % (splits * k_tile(p))) != 0) return -2;
     if (const int bn = big_tile_width(p, M, N, K, splits, true))
-        return launch_linear_big(p, bn, A, W, nullptr, part, M, N, K, splits, 0, true, stream);
+        return launch_linear_big(p, bn, A, W, nullptr, part, M, N, K, splits, 0, true, stream, wexp);
     return launch_linear_partial_classic(p, A, W, part, M, N, K, splits, stream, wexp);
 }
 

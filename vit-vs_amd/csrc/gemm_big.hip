@@ -29,6 +29,7 @@
 
 #include "gemm_core.h"
 #include "kernels.h"
+#include "probe.h"
 
 namespace vitvs {
 
@@ -46,11 +47,15 @@ struct BigTile {
     static constexpr int STAGE = 2 * A_SLOT + 2 * B_SLOT;
     static constexpr int RING = 2 * STAGE;
     static constexpr int WAVE_REGION = RING / 8;                      // epilogue image of one wave
-    static constexpr int BIAS_OFFSET = RING;                          // the tile's BN bias values (fp32) behind the ring
-    static constexpr int LDS_BYTES = RING + BN * 4;
+    static constexpr int BIAS_OFFSET = RING;                          // the tile's BN bias values (fp32) behind the ring ...
+    // ... for the epilogues that add a bias, and only where the 512 bytes do not push the footprint over half of the CU's
+    // 160 KB (the 192 x 128 tile's ring is exactly 80 KB: with the bias area two such workgroups — two queues, a neighbouring
+    // launch — could no longer share a CU; that tile reads its column terms from memory at the start of the epilogue instead)
+    static constexpr bool bias_in_lds(bool has_bias) { return has_bias && !(RING <= 80 * 1024 && RING + BN * 4 > 80 * 1024); }
+    static constexpr int lds_bytes(bool has_bias) { return RING + (bias_in_lds(has_bias) ? BN * 4 : 0); }
     static_assert(WGM * WGN == 8 && MT % 2 == 0 && NT % 2 == 0, "8 waves, even tile counts");
     static_assert(A_ROWS % 8 == 0 && B_ROWS % 8 == 0 && BH % 8 == 0 && AH % 8 == 0, "half slots are made of 8-row copies");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(RING + BN * 4 <= 160 * 1024, "LDS budget");
 };
 
 // 8-row group of a half slot that copy j of wave `wave` fills: G groups, L = ceil(G / 8) copies per wave.  Whole rounds keep
@@ -75,6 +80,11 @@ struct BigStore {      // out[m][n] = act(sum + bias[n]) in the operand type
     __device__ __forceinline__ f32x4 apply(f32x4 v, float4 b) const {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         if (gelu) {
+            if constexpr (kSplit<T>) {      // f16x2 keeps fp32-class outputs: libm erff, as linear_kernel's fp32 / f16x2 epilogues
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
+                return v;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26), as linear_kernel's 16-bit epilogue
                 const float x = fabsf(v[i]) * 0.70710678118654752440f;
@@ -101,13 +111,18 @@ struct BigPartial {    // part[z][m][n] = raw fp32 sums of k slice z
 // the k-loop goes to g_big_probe (3 words per workgroup) when it is set.
 __device__ int g_big_probe_flags;
 __device__ unsigned long long* g_big_probe;
+extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_big_probe(int flags, void* stamps) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe_flags), &flags, sizeof(flags)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe), &stamps, sizeof(stamps)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 template <typename T, class Tile, class Epi>
 __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                            typename Epi::Out* __restrict__ out, const float* __restrict__ bias,
                                                            int M, int N, int K, int flags, int slots) {
-    // flags: [31:24] k-tiles per split-K slice, [23:16] column tiles, [15:8] slices, [0] gelu; slots: [15:0] workgroups in
+    // flags: [31:24] k-tiles per split-K slice, [23:16] column tiles, [15:8] slices, [5:1] e (f16x2: the weights carry 2^e, the sums
+    // leave multiplied by 2^-e), [0] gelu; slots: [15:0] workgroups in
     // the grid (a multiple of 8, at most one per CU), [31:16] XCD map (below).  PERSISTENT workgroups: the slots / 8
     // workgroups of an XCD walk that XCD's tile list with stride slots / 8; a tile's output stores drain while the
     // workgroup already requests the next tile's operands.
@@ -147,11 +162,11 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
     bool first_tile = true;
-#ifdef VITVS_PROBE
-    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long probe_t1 = 0, probe_t2 = 0;
-    const bool probe_nostore = (g_big_probe_flags & 1) != 0;
-#endif
+    VITVS_IF_PROBE(
+        const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long probe_t1 = 0, probe_t2 = 0;
+        const bool probe_nostore = (g_big_probe_flags & 1) != 0;
+    )
   for (int it = local; it < blk_tiles; it += stride) {
     int tz, ty, tx;
     if (xmap == 0) {
@@ -233,20 +248,24 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     // waiting for anything it would not wait for anyway — where the epilogue used to start with a dependent global load of
     // its column terms (1 - 1.3 us per tile between the last k-tile and the first output store: profiles/r04_notes.md section 4).
     // Inline asm: for an ordinary load hipcc would drain every LDS-DMA copy in flight at the load's first use.
-    u32x4 bias_raw = {0u, 0u, 0u, 0u};
-    const bool bias_lane = Epi::HAS_BIAS && wave == 0 && lane < Tile::BN / 4;
-    if constexpr (Epi::HAS_BIAS) {
-        if (bias_lane) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_raw) : "v"(bias + n0 + 4 * lane) : "memory");
+    // The asm's output is defined, as far as hipcc knows, the moment it is issued, while the data lands at the counted wait
+    // below: EVERY lane issues the load (address clamped into the tile's columns) into an early-clobber output, so there is no
+    // conditional definition whose merge with an initial value (a register copy before the data has landed) hipcc could place
+    // between the two; the value is next named behind the wait.
+    constexpr bool BIAS_LDS = Tile::bias_in_lds(Epi::HAS_BIAS);
+    u32x4 bias_raw;
+    const bool bias_lane = BIAS_LDS && wave == 0 && lane < Tile::BN / 4;
+    if constexpr (BIAS_LDS) {
+        const float* bsrc = bias + n0 + 4 * min(lane, Tile::BN / 4 - 1);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bias_raw) : "v"(bsrc) : "memory");
     }
     // ---- prologue: k-tile 0 whole, k-tile 1's first halves, in the steady-state order
     issue_a(0, 0); issue_b(0, 0); issue_b(1, 0); issue_a(1, 0);
     issue_a(0, 1); issue_b(0, 1);
     wait_vmcnt<FULL>();                                  // A0(0), B0(0) have landed (this wave's copies)
-    if constexpr (Epi::HAS_BIAS) {
-        if (bias_lane) {
-            asm volatile("" : "+v"(bias_raw));           // (the wait above retired the load: it is older than every copy)
-            *reinterpret_cast<u32x4*>(smem + Tile::BIAS_OFFSET + 16 * lane) = bias_raw;
-        }
+    if constexpr (BIAS_LDS) {
+        asm volatile("" : "+v"(bias_raw));               // (the wait above retired the load: it is older than every copy)
+        if (bias_lane) *reinterpret_cast<u32x4*>(smem + Tile::BIAS_OFFSET + 16 * lane) = bias_raw;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in LDS before the barriers that follow
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -254,9 +273,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     __builtin_amdgcn_s_barrier();                        // ... and every other wave's
     if (wave >= 4) __builtin_amdgcn_s_barrier();         // stagger: the second group runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-#ifdef VITVS_PROBE
-    if (probe_t1 == 0) probe_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
+    VITVS_IF_PROBE(if (probe_t1 == 0) probe_t1 = __builtin_amdgcn_s_memrealtime();)
 
     // fragment registers: the current A half, both B halves
     u32x4 xa[MT / 2][2], wb[2][NT / 2][2];
@@ -279,14 +296,27 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     };
     auto mfma_quadrant = [&](int ha, int hb) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (kSplit<T>) {
+            // f16x2: fragment 0 = the hi halves of the k-tile's 32 k, fragment 1 = the lo halves (common.h): lo.hi + hi.lo, then
+            // hi.hi; term-outer so that the three MFMAs into one accumulator are a quadrant's other tiles apart
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int ni = 0; ni < NT / 2; ++ni)
+                for (int ni = 0; ni < NT / 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MT / 2; ++mi)
-                    acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi] =
-                        mma_chunk<T>(acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi], wb[hb][ni][ks], xa[mi][ks]);
+                    for (int mi = 0; mi < MT / 2; ++mi)
+                        acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi] =
+                            mma_chunk<f16>(acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi], wb[hb][ni][term == 0 ? 1 : 0], xa[mi][term == 1 ? 1 : 0]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < NT / 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MT / 2; ++mi)
+                        acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi] =
+                            mma_chunk<T>(acc[hb * (NT / 2) + ni][ha * (MT / 2) + mi], wb[hb][ni][ks], xa[mi][ks]);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // one phase = LOAD segment | barrier | MFMA segment | barrier
@@ -334,9 +364,7 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
 #undef VITVS_BIG_PHASE
     if (wave < 4) __builtin_amdgcn_s_barrier();          // the first group's matching extra barrier
     __builtin_amdgcn_sched_barrier(0);
-#ifdef VITVS_PROBE
-    probe_t2 = __builtin_amdgcn_s_memrealtime();
-#endif
+    VITVS_IF_PROBE(probe_t2 = __builtin_amdgcn_s_memrealtime();)
     // every wave has passed its last LDS read and every copy has landed (vmcnt 0 above): the ring is free
 
     // ---- epilogue through a wave-private LDS image, then whole-row stores
@@ -346,7 +374,14 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     asm volatile("" : "+v"(lane_e));
     const int l15e = lane_e & 15, ge = lane_e >> 4;
     typedef typename Epi::Out O;
-    constexpr int ES = (int)sizeof(O);
+    constexpr int ES = kSplit<O> ? 4 : (int)sizeof(O);             // bytes per logical output column (f16x2: an fp16 hi / lo pair)
+    if constexpr (kSplit<T>) {
+        const float wsc = __uint_as_float((127u - ((fl >> 1) & 31u)) << 23);   // 2^-e, exact
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[ni][mi] *= wsc;
+    }
     // the wave's NT column tiles leave in groups of NTG whose row segment is a power-of-two number of 16-byte chunks
     // (NT = 4: one group of 128 / 256 bytes per row; NT = 6, the 192-column tile: three groups of 64 / 128 bytes)
     constexpr int NTG = (NT % 4 == 0) ? 4 : 2, NCG = NT / NTG;
@@ -359,11 +394,12 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
     float4 col[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
-        if constexpr (Epi::HAS_BIAS) col[ni] = *reinterpret_cast<const float4*>(smem + Tile::BIAS_OFFSET + 4 * (wc * (NT * 16) + ni * 16 + 4 * ge));
+        if constexpr (BIAS_LDS) col[ni] = *reinterpret_cast<const float4*>(smem + Tile::BIAS_OFFSET + 4 * (wc * (NT * 16) + ni * 16 + 4 * ge));
+        else if constexpr (Epi::HAS_BIAS) col[ni] = *reinterpret_cast<const float4*>(bias + n0 + wc * (NT * 16) + ni * 16 + 4 * ge);   // (every copy has landed: an ordinary load)
         else col[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     unsigned char* img = smem + wave * Tile::WAVE_REGION;
-    O* obase = out + (size_t)tz * M * N;
+    unsigned char* obase = reinterpret_cast<unsigned char*>(out) + (size_t)tz * M * N * ES;
     const int wm0 = m0 + wr * (MT * 16), wn0 = n0 + wc * (NT * 16);
     constexpr int ROWS_PER_INST = 64 / CHUNKS;                     // rows one 64-lane 16-byte access covers
 #pragma unroll
@@ -377,7 +413,15 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
                 const int mi = pass * PASS_MT + mp, ni = cg * NTG + nl;
                 const f32x4 v = epi.apply(acc[ni][mi], col[ni]);
                 const int row = mp * 16 + l15e;
-                if constexpr (ES == 4) {
+                if constexpr (kSplit<O>) {
+                    // the image row has the layout of memory: per 32 columns [hi | lo] (128 bytes = 8 chunks); this lane's 4
+                    // columns nl * 16 + 4 ge .. + 3 are 8 bytes of a hi chunk and 8 bytes of the lo chunk 4 further on
+                    const int c = nl * 16 + 4 * ge;
+                    const int chunk = ((c >> 5) << 3) + ((c & 31) >> 3);
+                    const Split4 h = split4(v);
+                    *reinterpret_cast<f16x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4) + (ge & 1) * 8) = h.hi;
+                    *reinterpret_cast<f16x4*>(img + row * ROW_BYTES + (((chunk + 4) ^ (row & (CHUNKS - 1))) << 4) + (ge & 1) * 8) = h.lo;
+                } else if constexpr (ES == 4) {
                     const int chunk = nl * 4 + ge;
                     *reinterpret_cast<f32x4*>(img + row * ROW_BYTES + ((chunk ^ (row & (CHUNKS - 1))) << 4)) = v;
                 } else {
@@ -408,31 +452,23 @@ __global__ __launch_bounds__(512, 2) void linear_big_kernel(const T* __restrict_
                 // write-through (sc1): the rows leave for memory as they are stored instead of waiting, dirty in this XCD's
                 // L2, for the write-back at the kernel boundary (measured -3 ... -7 % on these launches: all of a tile's
                 // output is produced at its very end, so there is nothing for a write-back cache to merge)
-#ifdef VITVS_PROBE
-                if (probe_nostore) { asm volatile("" :: "v"(rowv[i])); continue; }
-#endif
+                VITVS_IF_PROBE(if (probe_nostore) { asm volatile("" :: "v"(rowv[i])); continue; })
                 if (m < M)
-                    store_out16<true>(reinterpret_cast<unsigned char*>(obase + (size_t)m * N + wn0 + cg * NTG * 16) + chunk * 16, rowv[i]);
+                    store_out16<true>(obase + ((size_t)m * N + wn0 + cg * NTG * 16) * ES + chunk * 16, rowv[i]);
             }
         }
         if (pass + 1 < MT / PASS_MT || cg + 1 < NCG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
   }   // next tile of this workgroup
-#ifdef VITVS_PROBE
-    if (g_big_probe && tid == 0) {
-        unsigned long long* dst = g_big_probe + 4 * (size_t)blockIdx.x;
-        dst[0] = probe_t0; dst[1] = probe_t1; dst[2] = probe_t2; dst[3] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
+    VITVS_IF_PROBE(
+        if (g_big_probe && tid == 0) {
+            unsigned long long* dst = g_big_probe + 4 * (size_t)blockIdx.x;
+            dst[0] = probe_t0; dst[1] = probe_t1; dst[2] = probe_t2; dst[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    )
 }
 
-#ifdef VITVS_PROBE
-extern "C" __attribute__((visibility("default"))) int vitvs_debug_set_big_probe(int flags, void* stamps) {
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe_flags), &flags, sizeof(flags)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_big_probe), &stamps, sizeof(stamps)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------- launch side
 typedef BigTile<2, 4, 8, 4> Tile256x256;
@@ -443,11 +479,13 @@ typedef BigTile<2, 4, 6, 4> Tile192x256;      // width code 1256 (192 rows x 256
 
 template <typename T, class Tile, class Epi>
 static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const float* bias, int M, int N, int K, int splits,
-                          int gelu, hipStream_t stream) {
+                          int gelu, hipStream_t stream, int wexp = 0) {
+    // (f16x2: K counts fp16 per row, two per logical k; a k-tile is 32 logical k)
     static std::atomic<unsigned long long> raised{0};
-    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_big_kernel<T, Tile, Epi>), Tile::LDS_BYTES, raised)) return -1;
+    constexpr int LDS_BYTES = Tile::lds_bytes(Epi::HAS_BIAS);
+    if (raise_lds_limit(reinterpret_cast<const void*>(&linear_big_kernel<T, Tile, Epi>), LDS_BYTES, raised)) return -1;
     const int nx = N / Tile::BN, ny = (M + Tile::BM - 1) / Tile::BM, nk = K / splits / 64;
-    if (N % Tile::BN || K % (splits * 64) || nk < 2 || nk > 255 || nx > 255 || splits > 255) return -2;
+    if (N % Tile::BN || K % (splits * 64) || nk < 2 || nk > 255 || nx > 255 || splits > 255 || wexp < 0 || wexp > 31) return -2;
     const long tiles = (long)nx * ny * splits;
     const int slots = (int)std::min<long>(8 * ((tiles + 7) / 8), 256);       // one workgroup per CU at most
     // XCD map (see the kernel): blocks of an XR x (8 / XR) XCD grid when CUs walk several tiles; among the grids whose
@@ -464,8 +502,8 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
             if (bytes < best) { best = bytes; xmap = xr; }
         }
     }
-    launch(linear_big_kernel<T, Tile, Epi>, dim3((unsigned)slots), dim3(512), Tile::LDS_BYTES, stream, A, W, out, bias, M, N, K,
-           (int)(((unsigned)nk << 24) | ((unsigned)nx << 16) | ((unsigned)splits << 8) | (unsigned)(gelu & 1)),
+    launch(linear_big_kernel<T, Tile, Epi>, dim3((unsigned)slots), dim3(512), LDS_BYTES, stream, A, W, out, bias, M, N, K,
+           (int)(((unsigned)nk << 24) | ((unsigned)nx << 16) | ((unsigned)splits << 8) | ((unsigned)wexp << 1) | (unsigned)(gelu & 1)),
            (int)((unsigned)slots | ((unsigned)xmap << 16)));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -476,7 +514,11 @@ static int launch_big_one(const T* A, const T* W, typename Epi::Out* out, const 
 // end: ~8 us at 6274 x 2304) — the rule below is that model with the relative tile costs measured.
 // Returns 0 (use gemm.hip), the column width 256, 192 or 128 of a 256-row tile, or 1192 / 1256 for the 192 x 128 / 192 x 256 tile.
 int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
-    if (!plain16(p) || splits < 1 || K % (splits * 64) || K / splits < 128 || K / splits / 64 > 255) return 0;
+    if (p == PREC_F32 || splits < 1) return 0;
+    // f16x2 runs the same kernels on rows of 2 K fp16 (a k-tile = 32 logical k, three MFMAs per k-step): the tile rule below is
+    // about rows, columns and rounds of workgroups, which do not change; only the k-tile count does
+    const int kt = (p == PREC_X2 ? 2 : 1) * K;
+    if (kt % (splits * 64) || kt / splits < 128 || kt / splits / 64 > 255) return 0;
     // The 64-row tiles of gemm.hip keep the layers they cover in ONE round of <= 256 workgroups (788 x 2304: 7.9 us there,
     // 11.9 us on 256 x 128 tiles); where they need a second round the 256-row tiles win from 64 tiles up (985 x 2304: 18.4 vs
     // 11.9 us).  Between the tile families of this file the busiest CU's share decides (below).
@@ -523,28 +565,29 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial) {
 
 template <typename T>
 static int launch_big_t(int bn, const T* A, const T* W, const float* bias, void* out, int M, int N, int K, int splits, int gelu,
-                        bool partial, hipStream_t stream) {
+                        bool partial, hipStream_t stream, int wexp = 0) {
     if (bn == 1256) {
-        if (partial) return launch_big_one<T, Tile192x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
-        return launch_big_one<T, Tile192x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+        if (partial) return launch_big_one<T, Tile192x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream, wexp);
+        return launch_big_one<T, Tile192x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream, wexp);
     }
     if (bn == 1192) {
-        if (partial) return launch_big_one<T, Tile192x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
-        return launch_big_one<T, Tile192x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+        if (partial) return launch_big_one<T, Tile192x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream, wexp);
+        return launch_big_one<T, Tile192x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream, wexp);
     }
     if (partial) {
-        if (bn == 256) return launch_big_one<T, Tile256x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
-        if (bn == 192) return launch_big_one<T, Tile256x192, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
-        return launch_big_one<T, Tile256x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream);
+        if (bn == 256) return launch_big_one<T, Tile256x256, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream, wexp);
+        if (bn == 192) return launch_big_one<T, Tile256x192, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream, wexp);
+        return launch_big_one<T, Tile256x128, BigPartial>(A, W, (float*)out, nullptr, M, N, K, splits, 0, stream, wexp);
     }
-    if (bn == 256) return launch_big_one<T, Tile256x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
-    if (bn == 192) return launch_big_one<T, Tile256x192, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
-    return launch_big_one<T, Tile256x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream);
+    if (bn == 256) return launch_big_one<T, Tile256x256, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream, wexp);
+    if (bn == 192) return launch_big_one<T, Tile256x192, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream, wexp);
+    return launch_big_one<T, Tile256x128, BigStore<T>>(A, W, (T*)out, bias, M, N, K, 1, gelu, stream, wexp);
 }
 
 int launch_linear_big(Precision p, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                      int splits, int gelu, bool partial, hipStream_t stream) {
-    if ((long long)M * K * 2 >= (1ll << 32) || (long long)N * K * 2 >= (1ll << 32)) return -2;   // 32-bit operand offsets
+                      int splits, int gelu, bool partial, hipStream_t stream, int wexp) {
+    if ((long long)M * K * (long long)elem_size(p) >= (1ll << 32) || (long long)N * K * (long long)elem_size(p) >= (1ll << 32)) return -2;   // 32-bit operand offsets
+    if (p == PREC_X2) return launch_big_t<hx2>(bn, (const hx2*)A, (const hx2*)W, bias, out, M, N, 2 * K, splits, gelu, partial, stream, wexp);
     if (p == PREC_BF16) return launch_big_t<bf16>(bn, (const bf16*)A, (const bf16*)W, bias, out, M, N, K, splits, gelu, partial, stream);
     if (p == PREC_F16) return launch_big_t<f16>(bn, (const f16*)A, (const f16*)W, bias, out, M, N, K, splits, gelu, partial, stream);
     return -2;

@@ -97,7 +97,7 @@ int big_tile_width(Precision p, int M, int N, int K, int splits, bool partial);
 int linear_tile_plan(Precision p, int M, int N, int K, int splits, bool partial, int out[3]);
 // partial = false: out[m][n] = act(sum + bias[n]) in precision p; partial = true: out = fp32 part[z][m][n], z < splits.
 int launch_linear_big(Precision p, int bn, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                      int splits, int gelu, bool partial, hipStream_t stream);
+                      int splits, int gelu, bool partial, hipStream_t stream, int wexp = 0);
 
 // ---- elementwise.hip -----------------------------------------------------------------------
 struct PatchifyArgs {
@@ -159,6 +159,11 @@ int launch_descriptors(const float* x, float* dn, float* raw, float* sqnorm_ws, 
 // in-stream copy of caller frames from the handle's pinned staging memory (device-visible host memory) to device memory —
 // one short launch on the update's own stream instead of a copy-engine command and its queue hops.
 int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t stream);
+
+// Experiment hook (tools/l2_warm_probe.py): every XCD's private L2 reads all `bytes` of `p` (256 workgroups,
+// workgroup L on XCD L % 8 walks the 32nd share L / 8 of the buffer with 16-byte loads), so that a launch that follows finds its
+// operand in L2 instead of the Infinity Cache.  share_xcds != 0: XCD x touches only the x-th eighth.
+int launch_touch(const void* p, size_t bytes, int share_xcds, hipStream_t stream);
 
 // dst[r][:] = src[r][:] / max(||src[r]||, 1e-8) for fp32 rows of width Dp (caller descriptors).
 int launch_normalize_rows(const float* src, float* dst, int rows, int Dp, hipStream_t stream);

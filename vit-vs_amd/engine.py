@@ -374,7 +374,45 @@ class Engine:
                                              p(v), p(st))
         self._check(rc, "vitvs_compute_velocity")
         self._last_tokens = self.tokens
+        self._last_host_pairs = n
         return v, st
+
+    def reselect_host(self, mode: int, selection=None, num_pairs: Optional[int] = None):
+        """``vitvs_reselect``: the control law again, for another selection, on what the last ``compute_velocity_host`` left in
+        the handle (arg-max keys, depth image, intrinsics) — the second half of the reference's update when the draw happens on
+        the host between the correspondence and the law (vitvs_v2.py:127-141).  numpy ``(v_c [n, 6], status [n])``."""
+        n = self._last_host_pairs
+        k = self._num_pairs(num_pairs)
+        sel = cnt = None
+        if mode == _lib.SELECT_EXPLICIT:
+            rows = selection if isinstance(selection, (list, tuple)) else [selection]
+            if len(rows) != n:
+                raise VitvsError("one id list per pair expected")
+            sel = np.zeros((n, k), np.int32)
+            cnt = np.zeros(n, np.int32)
+            for b, ids in enumerate(rows):
+                ids = np.asarray(ids, np.int32).reshape(-1)[:k]
+                sel[b, :ids.size] = ids
+                cnt[b] = ids.size
+        elif mode == _lib.SELECT_ORDER:
+            sel = np.ascontiguousarray(np.asarray(selection, np.int32).reshape(n, self.tokens))
+        v = np.zeros((n, 6), np.float64)
+        st = np.zeros(n, np.int32)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._check(self.lib.vitvs_reselect(self.handle, mode, p(sel), p(cnt), k, p(v), p(st)), "vitvs_reselect")
+        return v, st
+
+    def last_tables(self, n_pairs: int = 1) -> dict:
+        """``nn_1``, ``nn_2`` (int32) and ``sim_1`` (float32) [n, T] of the last servo call; after ``compute_velocity_host`` they
+        come from host memory (the handle's pinned block), no device call."""
+        t = getattr(self, "_last_tokens", self.tokens)
+        nn1 = np.empty((n_pairs, t), np.int32)
+        nn2 = np.empty((n_pairs, t), np.int32)
+        sim1 = np.empty((n_pairs, t), np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self.lib.vitvs_last_details(self.handle, n_pairs, p(nn1), p(nn2), p(sim1), None, None, None, None, None)
+        self._check(rc, "vitvs_last_details")
+        return dict(nn_1=nn1, nn_2=nn2, sim_1=sim1)
 
     def last_features(self, n_pairs: int = 1) -> dict:
         """``info``, ``s_uv`` and ``feat`` of the last servo call — what ``detect_features`` returns is made of

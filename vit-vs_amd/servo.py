@@ -113,23 +113,44 @@ def find_correspondences_batch(engine: Engine, descriptors1: torch.Tensor, descr
 
 
 def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator, num_pairs=None):
-    """The reference's own sequence with ONE forward: descriptors of both frames, similarity + arg-max on the device,
-    the reference's sort + ``randperm`` draw on the host (same torch RNG stream), then the control law on the device
-    for the drawn tokens.  Frames may be numpy arrays or device tensors (``Controller._resized`` returns the latter)."""
+    """The reference's own sequence with ONE forward: similarity + arg-max on the device, the reference's sort + ``randperm``
+    draw on the host (same torch RNG stream), then the control law on the device for the drawn tokens.
+
+    Host arrays in the engine's frame geometry (what the ``Controller``'s callbacks hold) take the two-call form: the host-pointer
+    update (``vitvs_compute_velocity``; its own law, on a fixed visiting order, is thrown away) leaves the arg-max tables in host
+    memory, the draw runs, and ``vitvs_reselect`` evaluates the law for the drawn tokens on the keys, depth image and intrinsics
+    the first call left in the handle.  Device tensors (``Controller._resized``) and other geometries go through the descriptor
+    seams (``extract_descriptors`` -> ``correspond`` -> ``servo_from_nn``), as before."""
     k = engine.params.num_pairs if num_pairs is None else int(num_pairs)
+
+    def draw(nn_1, nn_2, sim_1):
+        if generator is not None:
+            state = torch.get_rng_state()
+            torch.set_rng_state(generator.get_state())
+        try:
+            return _draw_like_the_reference(nn_1, nn_2, sim_1, engine.cfg.grid, k)
+        finally:
+            if generator is not None:
+                generator.set_state(torch.get_rng_state())
+                torch.set_rng_state(state)
+
+    host = (not torch.is_tensor(I_cur) and not torch.is_tensor(I_des) and I_des is not None
+            and tuple(np.asarray(I_cur).shape[-3:-1]) == tuple(engine.frame_size)
+            and (Z is None or (not torch.is_tensor(Z) and np.asarray(Z).dtype == np.uint16)))
+    if host:
+        order = np.arange(engine.tokens, dtype=np.int32)
+        _, st0 = engine.compute_velocity_host(I_cur, I_des, Z, K, _lib.SELECT_ORDER, order, num_pairs=k)
+        tab = engine.last_tables(1)
+        ids = draw(torch.from_numpy(tab["nn_1"][0]).long(), torch.from_numpy(tab["nn_2"][0]).long(), torch.from_numpy(tab["sim_1"][0]))
+        if ids is None:                                   # (None, None, None) in the reference
+            return np.zeros((1, 6)), np.array([_lib.STATUS_NO_CORRESPONDENCE], np.int32)
+        v, st = engine.reselect_host(_lib.SELECT_EXPLICIT, [ids.to(torch.int32).numpy()], num_pairs=k)
+        return v, st
     both = torch.cat([torch.as_tensor(I_des).to(engine.device), torch.as_tensor(I_cur).to(engine.device)])
     desc = engine.extract_descriptors(both)
     d1, d2 = desc[0, 0], desc[1, 0]
     nn_1, nn_2, sim_1 = engine.correspond(d1, d2)
-    if generator is not None:
-        state = torch.get_rng_state()
-        torch.set_rng_state(generator.get_state())
-    try:
-        ids = _draw_like_the_reference(nn_1.cpu().long(), nn_2.cpu().long(), sim_1.cpu(), engine.cfg.grid, k)
-    finally:
-        if generator is not None:
-            generator.set_state(torch.get_rng_state())
-            torch.set_rng_state(state)
+    ids = draw(nn_1.cpu().long(), nn_2.cpu().long(), sim_1.cpu())
     z = None if Z is None else torch.as_tensor(Z).reshape(engine.params.v_max, engine.params.u_max)
     if ids is None:                                       # (None, None, None) in the reference
         return np.zeros((1, 6)), np.array([_lib.STATUS_NO_CORRESPONDENCE], np.int32)
@@ -187,7 +208,9 @@ class Controller:
         self.velocity_vector_history = []
         self.max_velocity_vector_history = 200            # config.yaml:37
         self.last_status = None
-        self.generator = None                             # torch.Generator of the "order" draws (None: torch's global RNG)
+        self.generator = None                             # torch.Generator of the "order" / "reference" draws (None: torch's global RNG)
+        self._goal_key, self._goal_np = None, None        # a private, never-written copy of the goal frame: its address tells the
+                                                          # library that the staged goal is still the goal (option "reuse_goal_frames")
         self._rejected_geometries = set()                 # camera geometries the fused resize refused (set_frame_size), per engine
 
     # -- inputs (the reference's ROS callbacks)
@@ -242,6 +265,15 @@ class Controller:
         if self.latest_image is None:
             return None, None
         cur, des = self._path_frames(self.latest_pil_image, self.goal_image)
+        if not torch.is_tensor(des):
+            # the goal image does not change from update to update (vitvs_v2.py:264): hand the library the SAME private buffer every
+            # time, so that it forwards the goal frame already in device memory instead of staging it again (its tokens are still
+            # recomputed on every update, like the reference does)
+            key = (id(self.goal_image), des.shape)
+            if self._goal_key != key:
+                self._goal_key, self._goal_np = key, np.array(des, dtype=np.uint8, copy=True, order="C")
+                self.engine.set_option("reuse_goal_frames", 1)
+            des = self._goal_np
         depth = self.latest_image_depth
         # the law needs a depth image; detect_features itself does not, so feed a dummy one if it is missing
         z = depth if depth is not None else np.zeros((self.params.v_max, self.params.u_max), np.uint16)
