@@ -43,8 +43,15 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15, "f16x2": 2.5e15, "fp32": 157.3e12}
 ELEM_BYTES = {"bf16": 2, "fp16": 2, "f16x2": 4, "fp32": 4}       # bytes per logical operand element (f16x2: an fp16 hi / lo pair)
 PEAK_HBM = 8.0e12
-TRAFFIC_PROFILE = os.path.join("profiles", "r04_pmc_traffic.json")   # separate rocprofv3 --pmc passes (tools/measure_round.sh)
-STATS_PROFILE = os.path.join("profiles", "r04_kernel_stats_bf16.csv")   # rocprofv3 --kernel-trace --stats of the same command
+# separate rocprofv3 --pmc passes / rocprofv3 --kernel-trace --stats of the same command (tools/measure_round.sh), per precision;
+# the newest committed round that has the file is quoted
+def _profile(name):
+    for r in ("r05", "r04"):
+        if os.path.isfile(os.path.join(ROOT, "profiles", f"{r}_{name}")):
+            return os.path.join("profiles", f"{r}_{name}")
+    return os.path.join("profiles", f"r05_{name}")
+TRAFFIC_PROFILES = {"bf16": "pmc_traffic.json", "f16x2": "pmc_traffic_f16x2.json"}
+STATS_PROFILES = {"bf16": "kernel_stats_bf16.csv", "f16x2": "kernel_stats_f16x2.csv"}
 
 
 # ----------------------------------------------------------------------------------------------- launcher
@@ -881,7 +888,9 @@ def run_rank(args):
                                                    orders[0, 0], _lib)
             eng_x2.close()
             if pipe is not None:
-                pipe_x2 = UpdatePipeline(cfg, params, sd, precision="f16x2", depth=in_flight, max_pairs=B, device=dev)
+                # (on the main pipeline's streams, idle now: three more high-priority streams would share the class's four hardware
+                # queues with them, and two slots that land on one queue take turns — measured 1614 instead of 2367 updates/s)
+                pipe_x2 = UpdatePipeline(cfg, params, sd, precision="f16x2", depth=in_flight, max_pairs=B, device=dev, streams=pipe.streams)
 
                 def x2_step(i):
                     pipe_x2.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
@@ -987,7 +996,7 @@ def run_rank(args):
         # 96-99.5 % arg-max agreement on trained-like weights where bf16 keeps 77-91 %); same protocol as `value`, fewer steps
         same_kernels_fp16 = None
         if world == 1 and rank == 0 and not args.no_secondary and not dense and args.precision == "bf16" and pipe is not None:
-            pipe16 = UpdatePipeline(cfg, params, sd, precision="fp16", depth=in_flight, max_pairs=B, device=dev)
+            pipe16 = UpdatePipeline(cfg, params, sd, precision="fp16", depth=in_flight, max_pairs=B, device=dev, streams=pipe.streams)
 
             def step16(i):
                 pipe16.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
@@ -1070,8 +1079,10 @@ def run_rank(args):
     # HBM traffic (PMC) comes from separate rocprofv3 --pmc passes of this same command, never from this run: the line
     # says which committed file and which commit of the kernels it was measured on, and mixes it into no live ratio.
     traffic, traffic_source = None, None
+    TRAFFIC_PROFILE = _profile(TRAFFIC_PROFILES.get(args.precision, "none"))
+    STATS_PROFILE = _profile(STATS_PROFILES.get(args.precision, "none"))
     pmc_path = os.path.join(ROOT, TRAFFIC_PROFILE)
-    if os.path.isfile(pmc_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1:
+    if os.path.isfile(pmc_path) and args.precision in TRAFFIC_PROFILES and args.config == "vitb16_224" and B == 1:
         with open(pmc_path) as fh:
             blob = json.load(fh)
         entry = blob.get("kernels", blob).get(symbol)
@@ -1085,7 +1096,7 @@ def run_rank(args):
     # profiles/ can be reconciled mechanically (it is a record of ANOTHER run, on another box of the pool: +-4 %)
     from_profile = None
     stats_path = os.path.join(ROOT, STATS_PROFILE)
-    if os.path.isfile(stats_path) and args.precision == "bf16" and args.config == "vitb16_224" and B == 1 and symbol:
+    if os.path.isfile(stats_path) and args.precision in STATS_PROFILES and args.config == "vitb16_224" and B == 1 and symbol:
         import csv
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from symbols import short as short_symbol          # rocprofv3's (mangled) kernel names -> the names used here

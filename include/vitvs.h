@@ -134,9 +134,9 @@ VITVS_API int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uin
 /* The host-pointer form is the reference's seam as it is called (numpy arrays in, a numpy twist out: vitvs_v2.py:464-523,
  * 588-632).  Per call the buffers are copied into a block of pinned, device-visible host memory the handle owns (plain memcpy):
  * the frames go on to device memory in one short copy launch each on the update's own stream, the depth image is copied after the
- * forward has been enqueued and read in place by the law's kernel (<= max_rows pixels), and the twist, the status and the detail
- * block (vitvs_last_details: everything but `selected` and `L`) are written into the pinned block by the device: one polled
- * wait, no copy-engine command.  Option "reuse_goal_frames" (vitvs_set_option, 0 / 1, default 0): while I_des repeats the
+ * forward has been enqueued — only the pixels the law can read, the tokens' patch centres — and read in place by the law's
+ * kernel, the twist and the status are written into the pinned block by that kernel and the detail block (vitvs_last_details:
+ * everything but `selected` and `L`) follows in one copy launch: one polled wait, no copy-engine command.  Option "reuse_goal_frames" (vitvs_set_option, 0 / 1, default 0): while I_des repeats the
  * previous call's ADDRESS (and frame count and geometry) the goal frames already staged in device memory are forwarded again as
  * they are — for callers that keep the goal image in a buffer they never write to (a servo loop's goal image is fixed:
  * vitvs_v2.py:264); the goal's tokens are still recomputed on every update, like the reference does.

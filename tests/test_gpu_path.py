@@ -1201,15 +1201,20 @@ def test_two_handles_interleaved():
     assert float((tb0 - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
-def test_host_pointer_entry_point_matches_device_entry_point():
+@pytest.mark.parametrize("key", ["vits16_224", "vits14_308"])
+def test_host_pointer_entry_point_matches_device_entry_point(key):
+    """vitvs_compute_velocity (host buffers through the handle's pinned block; of the depth image only the pixels the law can read —
+    the tokens' patch centres, computed on the host — are handed over) against the device-pointer call on the whole image: equal
+    bits, at two token grids (14 x 14 and 22 x 22 over the 640 x 480 depth image, holes included)."""
     import ctypes as C
-    cfg = config.baseline_config("vits16_224")
+    cfg = config.baseline_config(key)
     sd = weights.synthetic_state_dict(cfg, 0)
-    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
-    des, cur = synth.frame_pair(224, 20250705)
+    params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
+    des, cur = synth.frame_pair(cfg.img_size, 20250705)
     depth = synth.depth_pattern()
-    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=196).load_state_dict(sd)
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=cfg.tokens).load_state_dict(sd)
     vd, sd_ = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)
+    det_d = eng.last_details(1)
     K = np.array(params.intrinsics(), np.float64)
     v = np.zeros(6, np.float64)
     st = np.zeros(1, np.int32)
@@ -1218,6 +1223,26 @@ def test_host_pointer_entry_point_matches_device_entry_point():
                                         p(depth), p(K), _lib.SELECT_DENSE, None, None, 0, p(v), p(st))
     assert rc == 0 and int(st[0]) == int(sd_[0])
     assert np.array_equal(v, vd.cpu().numpy()[0])
+    # the detail block of a host-pointer call is served from the handle's pinned block (the law wrote it there): the same bits
+    det_h = eng.last_details(1)
+    for name in ("nn_1", "nn_2", "sim_1", "info", "s_uv", "feat", "selected", "L"):
+        assert np.array_equal(det_h[name], det_d[name]), name
+    # vitvs_reselect: the law again for a host-side draw, on what the host-pointer call left in the handle (keys, depth sites,
+    # intrinsics) == the one-call update with that explicit selection
+    mutual = np.nonzero(det_h["nn_2"][0][det_h["nn_1"][0]] == np.arange(cfg.tokens))[0]
+    ids = mutual[:: max(1, len(mutual) // params.num_pairs)][: params.num_pairs].astype(np.int32)
+    v_one, st_one = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_EXPLICIT, selection=[ids])
+    det_one = eng.last_details(1)
+    rc = eng.lib.vitvs_compute_velocity(eng.handle, 1, p(np.ascontiguousarray(cur)), p(np.ascontiguousarray(des)), 0,
+                                        p(depth), p(K), _lib.SELECT_DENSE, None, None, 0, p(v), p(st))
+    assert rc == 0
+    v_re, st_re = eng.reselect_host(_lib.SELECT_EXPLICIT, [ids])
+    assert int(st_re[0]) == int(st_one[0]) and np.array_equal(v_re[0], v_one.cpu().numpy()[0])
+    feat_re = eng.last_features(1)
+    assert np.array_equal(feat_re["s_uv"], det_one["s_uv"]) and np.array_equal(feat_re["feat"], det_one["feat"])
+    eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)    # a device-pointer velocity call ends that state
+    v_bad = np.zeros(6, np.float64)
+    assert eng.lib.vitvs_reselect(eng.handle, _lib.SELECT_DENSE, None, None, 0, p(v_bad), p(st)) == -5
     # the host-pointer goal cache: vitvs_set_goal, then I_des = NULL; equal to the device-pointer cached call
     eng.set_goal(des)
     vc_dev, _ = eng.compute_velocity(cur, None, depth, params.intrinsics(), mode=_lib.SELECT_DENSE)

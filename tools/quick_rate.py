@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1)
+    ap.add_argument("--no-hint", action="store_true", help="pipeline slots keep the one-stream tile plan (no in_flight hint)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = config.baseline_config(args.config)
@@ -77,7 +78,7 @@ def main():
     print(f"  sum of kernel durations {total_us:.1f} us/update")
     eng.close()
     if args.depth > 1:
-        pipe = UpdatePipeline(cfg, params, sd, precision=args.precision, depth=args.depth, max_pairs=B, device=dev)
+        pipe = UpdatePipeline(cfg, params, sd, precision=args.precision, depth=args.depth, max_pairs=B, device=dev, plan_hint=not args.no_hint)
         for i in range(30):
             pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % 32], None, False)
         pipe.synchronize()

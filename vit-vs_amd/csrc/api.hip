@@ -154,6 +154,8 @@ struct vitvs_handle {
     struct HostTables { int n_pairs = 0, T = 0; bool have_depth = false; } host_tables;   // what vitvs_reselect may build on
     unsigned char* det_block = nullptr; // device copy of the detail block (detail_pointers), one allocation
     size_t det_bytes = 0;
+    std::vector<int32_t> depth_sites;   // linear pixel index of every token's patch centre that lies inside the depth image (the only
+                                        // pixels the law reads: servo.hip token_pixel, restated on the host at creation)
     bool reuse_goal = false;            // option "reuse_goal_frames": I_des of a host-pointer call is not staged again while its address repeats
     const void* staged_des = nullptr;   // host address, frame count and geometry of the goal frames in st_des
     size_t staged_des_bytes = 0;
@@ -162,10 +164,9 @@ struct vitvs_handle {
 namespace {
 
 // The detail block — what vitvs_last_details hands out except `selected` and L — is one allocation laid out
-// info [P][8] i32 | s_uv [P][R][4] i32 | feat [P][R][4] f64 | nn_1 [P][T] i32 | nn_2 [P][T] i32 | sim_1 [P][T] f32.  The law's kernel
-// writes it in device memory, or — host-pointer calls — straight into the handle's pinned block (same layout), so that the
-// reference's return values (s_uv*, s_uv, the selected similarities, and the tables its host-side draw needs) reach the host with
-// the twist, without a copy launch or a device-to-host copy.
+// info [P][8] i32 | s_uv [P][R][4] i32 | feat [P][R][4] f64 | nn_1 [P][T] i32 | nn_2 [P][T] i32 | sim_1 [P][T] f32, so that a host-pointer
+// call can hand the reference's return values (s_uv*, s_uv, the selected similarities, and the tables its host-side draw needs)
+// to the host with ONE copy launch into the handle's pinned block (same layout) behind the law's kernel.
 void detail_pointers(vitvs_handle* h, unsigned char* base) {
     const size_t P = h->cfg.max_pairs, R = h->cfg.max_rows;
     h->info = reinterpret_cast<int32_t*>(base);
@@ -582,6 +583,22 @@ int vitvs_create(const vitvs_config* cfg, vitvs_handle** out) {
     h->hidden = 4 * cfg->dim;
     h->n_img_max = 2 * cfg->max_pairs;
     h->blk.resize(cfg->blocks);
+    {   // The depth pixels the law can read: the patch centre of each token in camera resolution — servo.hip token_pixel, the
+        // same operations in the same precisions (fp32 centre, fp64 scale, round half to even; vitvs_v2.py:511-513, 544-549).
+        // tests/test_gpu_path.py::test_host_pointer_entry_point_matches_device_entry_point holds the two restatements together.
+        const int g = (int)floor(sqrt((double)h->T));
+        if (g * g == h->T) {
+            const double scale = (double)cfg->img_size / (double)g;
+            const float scale_f = (float)scale, half_f = (float)(scale / 2.0);
+            const double sx = (double)cfg->u_max / (double)cfg->img_size, sy = (double)cfg->v_max / (double)cfg->img_size;
+            for (int tok = 0; tok < h->T; ++tok) {
+                volatile float rm = (float)(tok / g) * scale_f, cm = (float)(tok % g) * scale_f;   // (separately rounded product)
+                const float r = rm + half_f, cc = cm + half_f;
+                const long u = (long)rint((double)cc * sx), v = (long)rint((double)r * sy);
+                if (u >= 0 && u < cfg->u_max && v >= 0 && v < cfg->v_max) h->depth_sites.push_back((int32_t)(v * cfg->u_max + u));
+            }
+        }
+    }
     // hipGraph replay of the update is opt-in (VITVS_GRAPH=1, read once per handle): with kernel arguments in device
     // memory (HIP_FORCE_DEV_KERNARG=1, set by the Python package before HIP initialises) plain stream launches measured
     // 2 % FASTER than replaying the captured graph; the graph's use is a caller whose host thread cannot spare the
@@ -999,11 +1016,23 @@ struct UpdateArgs {
     int32_t* status;
     // host-pointer entry point: the caller's depth image is copied into the pinned staging block on the HOST, after the
     // forward's launches have been enqueued and before the law's launch (the only kernel that reads it): off the critical path
-    const void* late_src = nullptr;
-    void* late_dst = nullptr;
-    size_t late_bytes = 0;
+    // Only the pixels the law can ask for are copied: it looks the depth up at the patch CENTRE of a current-frame token
+    // (vitvs_v2.py:511-553, 566-586), i.e. at one of T fixed sites of the image (late_sites: linear pixel indices, the handle's
+    // depth_sites), so T 2-byte gathers stand for the 614 KB image.
+    const uint16_t* late_src = nullptr;
+    uint16_t* late_dst = nullptr;
+    const int32_t* late_sites = nullptr;
+    int late_count = 0, late_pairs = 0;
+    size_t late_stride = 0;                     // pixels per depth image
 };
-static inline void late_inputs(const UpdateArgs& u) { if (u.late_src) memcpy(u.late_dst, u.late_src, u.late_bytes); }
+static inline void late_inputs(const UpdateArgs& u) {
+    if (!u.late_src) return;
+    for (int b = 0; b < u.late_pairs; ++b) {
+        const uint16_t* src = u.late_src + (size_t)b * u.late_stride;
+        uint16_t* dst = u.late_dst + (size_t)b * u.late_stride;
+        for (int i = 0; i < u.late_count; ++i) dst[u.late_sites[i]] = src[u.late_sites[i]];
+    }
+}
 
 static int enqueue_update(vitvs_handle* h, const UpdateArgs& u, hipStream_t st) {
     const int n_des = u.des_shared ? 1 : u.n_pairs, n_img = n_des + u.n_pairs;
@@ -1061,7 +1090,7 @@ static int replay_update(vitvs_handle* h, UpdateArgs u, hipStream_t st) {
                                         (uintptr_t)u.Z_mm, (uintptr_t)u.K, (uintptr_t)u.select_mode, (uintptr_t)u.num_pairs,
                                         (uintptr_t)(u.selection != nullptr), (uintptr_t)(u.n_selected != nullptr),
                                         (uintptr_t)u.v_c, (uintptr_t)u.status, (uintptr_t)h->fr.in_h, (uintptr_t)h->fr.in_w,
-                                        (uintptr_t)h->info};          // (the detail block the law writes: device or pinned)
+                                        (uintptr_t)h->info};
     vitvs_handle::GraphEntry* ge = nullptr;
     for (auto& g : h->graphs)
         if (g.key == key) ge = &g;
@@ -1201,11 +1230,16 @@ int vitvs_compute_velocity(vitvs_handle* h, int32_t n_pairs, const uint8_t* I_cu
     }
     UpdateArgs u{n_pairs, des_shared, select_mode, np, h->st_cur, I_des ? h->st_des : nullptr, Z_mm ? hs.depth : nullptr, hs.K,
                  hs.sel, hs.nsel, hs.vc, hs.status};
-    if (Z_mm) { u.late_src = Z_mm; u.late_dst = hs.depth; u.late_bytes = (size_t)n_pairs * c.u_max * c.v_max * 2; }
-    detail_pointers(h, hs.det);                  // the law writes this call's details into the pinned block
+    if (Z_mm) {
+        u.late_src = Z_mm; u.late_dst = hs.depth; u.late_sites = h->depth_sites.data(); u.late_count = (int)h->depth_sites.size();
+        u.late_pairs = n_pairs; u.late_stride = (size_t)c.u_max * c.v_max;
+    }
     rc = velocity_update(h, u, st);
-    detail_pointers(h, h->det_block);
     if (rc) return rc;
+    // the detail block of this call -> the pinned block, one copy launch of 16-byte stores (measured: the law's kernel writing
+    // its ~20 small detail stores straight into host memory cost 60 us per update; one coalesced copy costs 3)
+    rc = launch_copy16(h->det_block, hs.det, h->det_bytes, st);
+    if (rc) return set_err(h, rc, "detail copy launch failed");
     if (int w = wait_stream(st)) return w;
     memcpy(v_c, hs.vc, (size_t)n_pairs * 6 * sizeof(double));
     memcpy(status, hs.status, (size_t)n_pairs * 4);
@@ -1237,11 +1271,11 @@ int vitvs_reselect(vitvs_handle* h, int32_t select_mode, const int32_t* selectio
     } else if (select_mode == VITVS_SELECT_ORDER) {
         memcpy(hs.sel, selection, (size_t)n_pairs * T * 4);
     }
-    detail_pointers(h, hs.det);
-    const int rc = run_servo(h, n_pairs, T, h->host_tables.have_depth ? hs.depth : nullptr, hs.K, select_mode, np, hs.sel, hs.nsel, hs.vc,
-                             hs.status, h->host_stream);
-    detail_pointers(h, h->det_block);
+    int rc = run_servo(h, n_pairs, T, h->host_tables.have_depth ? hs.depth : nullptr, hs.K, select_mode, np, hs.sel, hs.nsel, hs.vc,
+                       hs.status, h->host_stream);
     if (rc) return rc;
+    rc = launch_copy16(h->det_block, hs.det, h->det_bytes, h->host_stream);
+    if (rc) return set_err(h, rc, "detail copy launch failed");
     if (int w = wait_stream(h->host_stream)) return w;
     memcpy(v_c, hs.vc, (size_t)n_pairs * 6 * sizeof(double));
     memcpy(status, hs.status, (size_t)n_pairs * 4);

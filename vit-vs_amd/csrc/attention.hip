@@ -293,8 +293,11 @@ constexpr int kAttnStateFloats = 9 * 64 * 4;                // per wave: 8 x 16 
 // pipe — a third 32-row block of V^T whose rows are all ones, i.e. one more MFMA per 16-key step with a constant A operand —
 // instead of 32 vector adds per tile; the fast path's headroom test then takes the maximum of the shifted scores (16 v_max3)
 // BEFORE the exponentials rather than the sum of the probabilities after them.
+// (ONES needs 16 more accumulator registers: 187, over the 170 a wave may hold at three waves per SIMD — compiled for three it
+// spills 300 bytes per lane, and spill traffic between the hand-counted vmcnt waits breaks them — so the variant is built for
+// two workgroups per CU.)
 template <typename HT, bool ONES = false>
-__global__ __launch_bounds__(256, 3) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
+__global__ __launch_bounds__(256, ONES ? 2 : 3) void attention_16_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
                                                                    int D, int n_img, int per, int g_per_xcd, float qscale,
                                                                    float* __restrict__ ws, int* __restrict__ tickets) {
     typedef typename Vec16<HT>::x8 hx8;

@@ -70,6 +70,7 @@ class Engine:
         if rc != 0:
             raise VitvsError(f"vitvs_create failed ({rc}): {_lib.last_error(None)}")
         self.frame_size = (cfg.img_size, cfg.img_size)   # geometry of the frames the calls take (set_frame_size)
+        self._last_host_pairs = 1                         # pairs of the last host-pointer velocity call (reselect_host)
         self.tokens = self.lib.vitvs_tokens(self.handle)
         self.desc_dim = self.lib.vitvs_desc_dim(self.handle)
         assert self.tokens == cfg.tokens

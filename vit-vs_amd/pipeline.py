@@ -34,7 +34,7 @@ class UpdatePipeline:
     def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 3,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
                  plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True,
-                 stage_inputs: bool = False):
+                 stage_inputs: bool = False, streams: Optional[List[torch.cuda.Stream]] = None):
         if depth < 1:
             raise VitvsError("depth must be >= 1")
         self.depth = int(depth)
@@ -55,7 +55,12 @@ class UpdatePipeline:
         # the same four queues, and two slots that land on one queue run one after the other (measured: depth 3 at 2500
         # instead of 3300 updates/s, depending on what else the process had created).  High-priority streams draw from a pool
         # of their own, so up to four slots always get a queue each.
-        self.streams = [torch.cuda.Stream(device=self.device, priority=stream_priority) for _ in range(self.depth)]
+        # (`streams`: run on another pipeline's streams instead of creating more — a second pipeline of the same process, e.g. another
+        # precision measured beside the first, would otherwise put 2 x depth high-priority streams on the class's four queues.)
+        if streams is not None and len(streams) != self.depth:
+            raise VitvsError("streams: one per slot")
+        self.streams = list(streams) if streams is not None else \
+            [torch.cuda.Stream(device=self.device, priority=stream_priority) for _ in range(self.depth)]
         self.done = [torch.cuda.Event() for _ in range(self.depth)]
         n = max_pairs
         self.v = [torch.zeros((n, 6), dtype=torch.float64, device=self.device) for _ in range(self.depth)]
