@@ -976,8 +976,11 @@ def run_rank(args):
             controller_loop = dict(frames=f"{params.u_max}x{params.v_max} uint8 host arrays + uint16 depth, fused Pillow-exact resize",
                                    dtype=args.precision, note="Controller.ibvs() per update incl. the callbacks' hand-over, the draw, "
                                    "EMA and the feature arrays the reference's detect_features returns; one update in flight")
-            for sel_name in ("order", "reference"):
-                ctl = vservo.Controller(eng_c, goal_image=goal_cam, selection=sel_name)
+            eng_cx = Engine(cfg, params, precision="f16x2", max_pairs=1).load_state_dict(sd) if args.precision != "f16x2" else None
+            for sel_name, eng_l in (("order", eng_c), ("reference", eng_c), ("order_f16x2", eng_cx), ("reference_f16x2", eng_cx)):
+                if eng_l is None:
+                    continue
+                ctl = vservo.Controller(eng_l, goal_image=goal_cam, selection=sel_name.split("_")[0])
                 ctl.generator = torch.Generator().manual_seed(121)
                 n_loop, lat_c = 230, []
                 for i in range(n_loop):
@@ -991,6 +994,8 @@ def run_rank(args):
                                                  median_ms=round(float(np.median(lat_c)), 4), p90_ms=round(float(np.percentile(lat_c, 90)), 4),
                                                  v_c_is_set=ctl.v_c is not None, status=ctl.last_status)
             eng_c.close()
+            if eng_cx is not None:
+                eng_cx.close()
 
         # fp16: the same kernels on v_mfma_f32_16x16x32_f16 — the throughput dtype for trained checkpoints (DESIGN.md section 3:
         # 96-99.5 % arg-max agreement on trained-like weights where bf16 keeps 77-91 %); same protocol as `value`, fewer steps
@@ -1150,6 +1155,12 @@ def run_rank(args):
             from_profile["frac"] = round(by / (from_profile["avg_ns"] * 1e-9) / PEAK_HBM, 5)
             roof["recomputed_from_profile"] = from_profile
 
+    if host_buffers:
+        # a host-pointer call ends with the caller holding v_c, i.e. with a wait: its device-resident counterpart is the
+        # synchronised single update (latency_ms_with_host_sync), not the back-to-back stream of `sequential`
+        sync_ms = float(np.median(lat)) * 1e3
+        host_buffers["vs_sequential"] = round(host_buffers["value"] / (sequential["value"] if sequential else value), 4)
+        host_buffers["vs_device_resident_update_with_host_sync"] = round(sync_ms / host_buffers["ms_per_step"], 4)
     out = dict(
         metric="servo_updates_per_sec", value=round(value, 2), unit="updates/s", n_gpus=world, steps=args.steps,
         warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How closely do the fp32 / fp16 / bf16 modes follow the fp32 CPU oracle on YOUR checkpoint?
+"""How closely do the fp32 / f16x2 (split-f16) / fp16 / bf16 modes follow the fp32 CPU oracle on YOUR checkpoint?
 
 No pretrained weights can be fetched in the build environment, so the repository's own evidence about trained checkpoints is a
 stand-in (weights.trained_like_state_dict).  With a local DINO / DINOv2 / timm state dict this prints the same
@@ -69,7 +69,7 @@ def main():
           f"{np.median(top2[:, 1] - top2[:, 0]):.2e} min {(top2[:, 1] - top2[:, 0]).min():.2e}")
     depth = synth.depth_pattern()
     order = np.random.default_rng(1).permutation(t).astype(np.int32)
-    for precision in ("fp32", "fp16", "bf16"):
+    for precision in ("fp32", "f16x2", "fp16", "bf16"):
         eng = Engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
         v, st = eng.compute_velocity(cur, des, depth, params.intrinsics(), mode=_lib.SELECT_ORDER, selection=order[None])
         det = eng.last_details(1)
