@@ -100,7 +100,7 @@ def test_closed_loop_raw_twist_equals_the_oracle_update_by_update():
     assert identical == n_updates                                       # deterministic fixture: measured 12 of 12
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
 def test_closed_loop_converges_and_keeps_its_state(precision):
     cfg, params, sd, eng, scene, ctl, sim, goal_rgb = _setup(precision, "order")
     raw, status, feat_err = [], [], []

@@ -109,7 +109,7 @@ def test_eight_cameras_in_one_batched_call_equal_eight_controllers(rig):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "f16x2"])
 def test_eight_cameras_through_one_pipeline_equal_eight_controllers(rig, precision):
     """Three updates in flight (the arrangement bench.py measures `value` with): camera i's update is the one-stream update of a
     handle with the same tile plan, so also in the headline dtype every twist is bit-identical."""

@@ -314,3 +314,27 @@ def test_linear_partial_tile_families(lib, variant, M, N, K, slices):
     for z in range(slices):
         ref = A[:, z * ks:(z + 1) * ks].double() @ W[:, z * ks:(z + 1) * ks].double().t()
         assert _rel(part[z].cpu(), ref) <= TOL
+
+
+def test_linear_saturates_instead_of_overflowing(lib):
+    """Activations beyond the fp16 range: the hi half saturates at 65504 and the lo half carries the remainder (common.h split4), so
+    magnitudes up to 2 x 65504 stay finite and close (the plain fp16 mode turns them into infinities)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 64, 64, 64
+    A = _mk((M, K), g)
+    A[3, 5], A[10, 20], A[40, 63] = 9.0e4, -1.2e5, 7.0e4
+    W = _mk((N, K), g, K ** -0.5)
+    ref = A.double() @ W.double().t()
+    e = weight_exp(W)
+    Ad, Wd = to_x2(A).cuda(), to_x2(W, e).cuda()
+    assert torch.isfinite(Ad.float()).all()
+    out = torch.empty((M, 2 * N), dtype=torch.float16, device="cuda")
+    bias = torch.zeros(N, device="cuda")
+    lib.vitvs_op_weight_exponent(e)
+    rc = lib.vitvs_op_linear(X2, _p(Ad), _p(Wd), _p(bias), _p(out), M, N, K, 0, _stream())
+    lib.vitvs_op_weight_exponent(0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = from_x2(out.cpu())
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) <= 2e-4          # the remainder 90000 - 65504 = 24496 has its own 11 bits: 2^-11 * 24496 / 90000

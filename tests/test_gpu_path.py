@@ -1255,6 +1255,41 @@ def test_host_pointer_entry_point_matches_device_entry_point(key):
     assert eng.lib.vitvs_set_goal(eng.handle, 2, p(np.ascontiguousarray(des))) < 0       # more goal frames than max_pairs
 
 
+def test_reuse_goal_frames_option_of_the_host_pointer_call():
+    """Option "reuse_goal_frames": while I_des repeats the previous call's address the goal frame already staged in device memory is
+    forwarded again (its tokens are still recomputed): same bits as a fresh call; a new address is staged; and — the documented
+    price — a goal buffer rewritten IN PLACE is not seen until the option is off."""
+    import ctypes as C
+    cfg = config.baseline_config("vits16_224")
+    sd = weights.synthetic_state_dict(cfg, 0)
+    params = config.ServoParams(dino_input_size=224, use_feature_binning=False)
+    des, cur = synth.frame_pair(224, 20250705)
+    des2, _ = synth.frame_pair(224, 20250706)
+    depth = synth.depth_pattern()
+    eng = _engine(cfg, params, precision="fp32", max_pairs=1, max_rows=196).load_state_dict(sd)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    K = np.array(params.intrinsics(), np.float64)
+
+    def call(goal):
+        v, st = np.zeros(6), np.zeros(1, np.int32)
+        assert eng.lib.vitvs_compute_velocity(eng.handle, 1, p(cur), p(goal), 0, p(depth), p(K), _lib.SELECT_DENSE, None, None, 0, p(v), p(st)) == 0
+        return v.copy()
+    cur = np.ascontiguousarray(cur)
+    goal = np.array(des, copy=True, order="C")
+    v_fresh, v_other = call(goal), call(np.ascontiguousarray(des2))
+    assert not np.array_equal(v_fresh, v_other)
+    eng.set_option("reuse_goal_frames", 1)
+    assert np.array_equal(call(goal), v_fresh) and np.array_equal(call(goal), v_fresh)      # staged once, forwarded twice
+    other = np.ascontiguousarray(des2)
+    assert np.array_equal(call(other), v_other)                                               # another address: staged
+    assert np.array_equal(call(goal), v_fresh)
+    goal[...] = des2                                                                           # rewritten in place: NOT seen ...
+    assert np.array_equal(call(goal), v_fresh)
+    eng.set_option("reuse_goal_frames", 0)                                                     # ... until the option is off
+    assert np.array_equal(call(goal), v_other)
+    eng.close()
+
+
 # ----------------------------------------------------------------------------- host mirror of the reference interface
 @pytest.mark.parametrize("exact", EXACT)
 def test_controller_adapter_reproduces_reference_update(exact):

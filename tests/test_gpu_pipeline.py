@@ -29,7 +29,7 @@ def _orders(cfg, n, dev, seed=121):
     return torch.stack([torch.randperm(cfg.tokens, generator=gen) for _ in range(n)]).to(torch.int32).to(dev)[:, None]
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "f16x2"])
 @pytest.mark.parametrize("hint", [False, True])
 def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint):
     """11 updates over 4 different frame pairs and 11 visiting orders through a pipeline of depth 3 against the same updates,

@@ -165,9 +165,16 @@ def test_multi_controller_keeps_every_cameras_state_apart():
         mc.ibvs()
     assert mc.cameras[1].feature_failure_count == 8
     mc.ibvs()
+    # ... AFTER every camera of that round has been absorbed: camera 2 comes after the failing camera 1 in the round's loop, and N
+    # independent Controllers would each have taken their own step
+    mc.image_callback_depth(2, depth)
+    mc.image_callback_rgb(2, frame(60))
+    before = (len(mc.cameras[0].velocity_vector_history), len(mc.cameras[2].velocity_vector_history))
     with pytest.raises(RuntimeError, match="Persistent feature detection failure"):
         mc.ibvs()
-    assert mc.cameras[0].feature_failure_count == 0
+    assert mc.cameras[0].feature_failure_count == 0 and mc.cameras[1].feature_failure_count == 10
+    assert (len(mc.cameras[0].velocity_vector_history), len(mc.cameras[2].velocity_vector_history)) == (before[0] + 1, before[1] + 1)
+    assert mc.cameras[2].last_status == 0 and mc.cameras[2].v_c is not None
     # explicit ids per round
     mc2 = servo.MultiController(eng, goals[:2])
     mc2.image_callback_rgb(0, frame(1)); mc2.image_callback_rgb(1, frame(2))
@@ -177,3 +184,37 @@ def test_multi_controller_keeps_every_cameras_state_apart():
         servo.MultiController(eng, goals, selection="reference")
     with pytest.raises(ValueError):
         servo.MultiController(eng, [frame(0)] * 9)
+
+
+def test_controller_asks_for_a_refused_frame_geometry_only_once():
+    """A camera geometry the fused resize cannot take (``Engine.set_frame_size`` raises; the handle keeps its previous geometry) is
+    remembered: every attempt builds Pillow's tables, allocates and synchronises the device, so the fallback (the stand-alone
+    resize) must not pay for it on every control step."""
+    from vitvs_amd import config
+    from vitvs_amd.engine import VitvsError
+
+    class _Refusing:
+        def __init__(self):
+            self.params = config.ServoParams(dino_input_size=8, use_feature_binning=False)
+            self.cfg = type("C", (), dict(img_size=8, grid=2))()
+            self.asked, self.resized = [], 0
+            self.frame_size = (8, 8)
+
+        def set_frame_size(self, h=None, w=None):
+            if h is not None and (h, w) != (8, 8):
+                self.asked.append((h, w))
+                raise VitvsError("camera frame too large for the fused resize")
+            return self
+
+        def resize_frames(self, arr):
+            self.resized += 1
+            return [np.zeros((8, 8, 3), np.uint8)]
+
+    eng = _Refusing()
+    ctl = servo.Controller(eng, goal_image=np.zeros((480, 640, 3), np.uint8), selection="order")
+    for _ in range(5):
+        frames = ctl._path_frames(np.zeros((480, 640, 3), np.uint8), ctl.goal_image)
+        assert all(np.asarray(f).shape == (8, 8, 3) for f in frames)
+    assert eng.asked == [(480, 640)] and eng.resized == 10          # asked once, resized every time
+    ctl._path_frames(np.zeros((240, 320, 3), np.uint8), np.zeros((240, 320, 3), np.uint8))
+    assert eng.asked == [(480, 640), (240, 320)]                     # another geometry is another question
