@@ -216,7 +216,9 @@ def _attention_ref(qkv, n_img, N, H):
 
 @pytest.mark.parametrize("n_img,N,H,scale", [(2, 197, 6, 1.0), (2, 197, 12, 3.0), (1, 64, 2, 1.0), (1, 70, 1, 3.0), (2, 257, 2, 2.0),
                                              (1, 1370, 2, 1.0), (3, 5, 1, 1.0), (2, 530, 3, 2.0), (1, 700, 1, 4.0),
-                                             (1, 3137, 1, 1.0), (9, 197, 12, 1.0), (16, 485, 6, 1.0)])
+                                             (1, 3137, 1, 1.0), (9, 197, 12, 1.0), (16, 485, 6, 1.0),
+                                             # from 2048 tokens on: the 128-query kernel (tails of 1 key / 1 query row, several heads and images)
+                                             (2, 2049, 2, 2.0), (1, 2200, 3, 1.0), (2, 2048, 1, 3.0)])
 def test_attention(lib, n_img, N, H, scale):
     g = torch.Generator().manual_seed(N * 3 + H)
     D = H * 64
@@ -231,10 +233,12 @@ def test_attention(lib, n_img, N, H, scale):
     assert _rel(got, ref) <= 1e-5
 
 
-def test_attention_asymmetric_values_catch_transposed_operands(lib):
+@pytest.mark.parametrize("N", [130, 2100])
+def test_attention_asymmetric_values_catch_transposed_operands(lib, N):
     """V with a per-dimension ramp and one-hot attention: any key / dim permutation slip in the PV product (transposed LDS reads
-    through the window swizzle, permuted MFMA k-slots, the hi / lo windows) shows up as an O(1) error."""
-    N, H = 130, 1
+    through the window swizzle, permuted MFMA k-slots, the hi / lo windows) shows up as an O(1) error.  (130 tokens: the 16-query
+    kernel; 2100: the 128-query one.)"""
+    H = 1
     qkv = torch.zeros((N, 192), dtype=torch.float32)
     keys = torch.arange(N, dtype=torch.float32)
     qkv[:, 0] = 40.0

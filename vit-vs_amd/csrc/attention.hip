@@ -35,6 +35,17 @@ constexpr float kScaleLog2e = kAttnQScale;                        // hd^-0.5 * l
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; exp2(-inf) = 0
 __device__ __forceinline__ void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// lo halves of two weights whose hi halves are packed in `hi`: f16(p - hi), the subtraction exact in fp32.  One mixed-precision fma per
+// value (fp16 source widened inside the instruction, fp16 result written to its half of the destination) instead of widen + subtract +
+// narrow: the vector pipe is the long kernel's longer resource.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ inline f16x2 split_lo_pair(f16x2 hi, float p0, float p1) {
+    const unsigned h = __builtin_bit_cast(unsigned, hi);
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(p0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h), "v"(p1));
+    return __builtin_bit_cast(f16x2, d);
+}
 // max of three as ONE instruction: for fmaxf() on MFMA results hipcc first emits a canonicalising v_max_f32 x, x, x per
 // operand (32 extra vector instructions per key tile in a loop that is bound by vector issue)
 __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -696,6 +707,230 @@ __global__ __launch_bounds__(256, ONES ? 2 : 3) void attention_16_long_kernel(co
     )
 }
 
+// ------------------------------------------------------------------------------------ split-f16 (f16x2), long sequences
+// The 128-query arrangement of attention_16_long_kernel for hi / lo operands (N > 256: the 485 / 1370 / 3137 tokens of 308² / 518² /
+// 448² inputs): wave w = queries 32 w .. 32 w + 31 on the 32x32x16 MFMA, both contractions as lo.hi + hi.lo + hi.hi.  K / V tiles
+// of 32 KEYS (a key's row is 256 bytes here: 32 keys x 256 B of K and as much of V = 16 KB per stage) by LDS-DMA into a THREE-stage
+// ring with counted waits — two tiles in flight across every barrier, 48 KB of LDS — and at most 170 registers, so that THREE
+// workgroups share a CU: the first version of this kernel (64-key tiles, two stages, every V fragment of a tile in registers: 214
+// registers, two workgroups per CU) ran 2 x 3137 x 12 in 254 us, no faster than the generic kernel — its 600 workgroups needed a
+// second round on 512 slots and a one-tile prefetch distance was exposed on every tile; this form 235 us, 219 us with the softmax's
+// vector work trimmed (below).  Counters of that launch (profiles/r05_attention_x2_long_pmc.txt, r05_notes.md section 9): no LDS bank
+// conflicts, LDS array busy 12 % of the time; the matrix pipe busy 47 % of the kernel's cycles averaged over the chip and ~59 % on the
+// 88 CUs that hold three of the 600 workgroups (the others hold two and finish early); 49 % of a wave's life is issue stall behind
+// the other waves of its SIMD, 18 % parked on a wait.  Priority raised around the MFMA clusters (s_setprio) and scalar instead of
+// packed fp32 softmax arithmetic were measured on the same box and change nothing (+-1 %).
+// Per wave and key tile: 12 score MFMAs + 12 PV MFMAs (three times the 16-bit kernel's per key) and ~110 vector instructions (16
+// exponentials, the hi / lo split of P as one conversion and two mixed-precision fmas per pair), so the kernel keeps the plain online
+// softmax (fp32 statistics on raw scores, hd^-0.5 log2 e inside the exponent's fma, P split in registers at 2^8) — the 16-bit
+// kernel's shift-inside-the-MFMA and key-range hand-off buy nothing here.
+//   K image: chunk c (16 bytes) of row r at slot c ^ (r & 15) (tile256_off), applied to the copy's SOURCE chunk (LDS-DMA writes linearly)
+//   V image: 32-byte window w of row r at slot w ^ ((r & 3) << 1): the 16 (row, window) pieces one transposed read touches (8 rows x
+//            2 windows) fall two on each of the eight 32-byte bank windows
+// 1-D grid, XCD-aware item order (the query blocks of an (image, head) run on the XCD whose L2 already holds its K and V).
+__global__ __launch_bounds__(256, 3) void attention_x2_long_kernel(const hx2* __restrict__ qkv, hx2* __restrict__ out, int N, int D,
+                                                                   int n_img, int g_per_xcd) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STAGE = 2 * 32 * 256;                       // K tile then V tile, 32 keys each
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int H = D >> 6, nqb = (N + 127) >> 7, items = n_img * H * nqb, nt = (N + 31) >> 5;
+    const int item = (int)(blockIdx.x & 7) * g_per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= items) return;
+    const int pair = item / nqb;
+    const int img = pair / H, h = pair - img * H, q0 = (item - pair * nqb) * 128 + 32 * wave;
+    const unsigned char* qb = reinterpret_cast<const unsigned char*>(qkv);
+    const unsigned row_bytes = 12u * (unsigned)D;             // 3 D logical columns x (hi + lo)
+    const unsigned tile_bytes = 32u * row_bytes;
+    const unsigned head_off = (unsigned)(img * N) * row_bytes + (unsigned)h * 256u;
+    const unsigned k_off = head_off + 4u * (unsigned)D, v_off = head_off + 8u * (unsigned)D;
+
+    // this wave's LDS-DMA copies per tile: rows 8 wave .. 8 wave + 7 of the K image and of the V image, 4 rows per copy
+    unsigned koff[2], voff[2];
+    int crow[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        crow[c] = 8 * wave + 4 * c + (lane >> 4);
+        const int sl = lane & 15;
+        koff[c] = k_off + (unsigned)crow[c] * row_bytes + 16u * (unsigned)(sl ^ (crow[c] & 15));
+        voff[c] = v_off + (unsigned)crow[c] * row_bytes + 32u * (unsigned)((sl >> 1) ^ ((crow[c] & 3) << 1)) + 16u * (unsigned)(sl & 1);
+    }
+    auto issue = [&](int t, int stage) {
+        unsigned char* dst = smem + stage * STAGE + (8 * wave) * 256;
+        if (t + 1 < nt) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] + (unsigned)t * tile_bytes)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] + (unsigned)t * tile_bytes)), (lds_ptr)(dst + 32 * 256 + c * 1024), 16, 0, 0);
+            }
+        } else {                                              // the sequence's last tile: rows past the end -> row N - 1
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned back = __umul24((unsigned)max(32 * t + crow[c] - (N - 1), 0), row_bytes);
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (koff[c] + (unsigned)t * tile_bytes - back)), (lds_ptr)(dst + c * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr)(qb + (voff[c] + (unsigned)t * tile_bytes - back)), (lds_ptr)(dst + 32 * 256 + c * 1024), 16, 0, 0);
+            }
+        }
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    // Q fragments (B operand of S^T = K Q^T): lane (r32, hh) holds Q[query r32][dims 16 ks + 8 hh .. + 7], hi and lo; ordinary loads
+    // AFTER the first copies and consumed (empty asm) before the loop, so that hipcc's wait for them is one wait in the prologue
+    // (inside the loop it would be vmcnt(0) on every tile: the ring drained)
+    u32x4 qraw[8];
+    {
+        const unsigned o = head_off + (unsigned)min(q0 + r32, N - 1) * row_bytes + 16u * (unsigned)hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned at = o + 128u * (unsigned)(ks >> 1) + 32u * (unsigned)(ks & 1);   // dims 16 ks + 8 hh: block ks >> 1, 32 bytes per 16 dims
+            qraw[2 * ks] = *reinterpret_cast<const u32x4*>(qb + at);
+            qraw[2 * ks + 1] = *reinterpret_cast<const u32x4*>(qb + at + 64u);
+        }
+    }
+    asm volatile("" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(qraw[4]), "+v"(qraw[5]), "+v"(qraw[6]), "+v"(qraw[7]));
+    f16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qh[ks] = __builtin_bit_cast(f16x8, qraw[2 * ks]); ql[ks] = __builtin_bit_cast(f16x8, qraw[2 * ks + 1]); }
+
+    // lane constants of the fragment reads
+    const int li = lane & 15, dh = (lane >> 4) & 1;
+    const int v_row = 4 * hh + (li >> 2);                     // key row inside a 16-key step (+ 8 for elements 4 .. 7)
+    const int v_sw = (li >> 2) << 1;                          // window swizzle of that row: (row & 3) << 1 (+ 8 rows keeps it)
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[db][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) wait_vmcnt4();                        // tile t has landed (this wave's copies): only tile t + 1's four are younger
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... every wave's; and everyone is done with tile t - 1
+        __builtin_amdgcn_sched_barrier(0);
+        const int slot2 = slot == 0 ? 2 : slot - 1;           // (slot + 2) % 3: the slot of tile t - 1, free behind the barrier
+        if (t + 2 < nt) issue(t + 2, slot2);
+        const unsigned char* ldsK = smem + slot * STAGE;
+        slot = slot == 2 ? 0 : slot + 1;
+        const int kb0 = t * 32;
+        // scores: acc_s[i] = S[key 32 t + (i & 3) + 8 (i >> 2) + 4 hh][query r32]
+        f32x16 acc_s;
+        {
+            f16x8 kh[4], kl[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 8 * (ks >> 1) + 2 * (ks & 1) + hh;     // 16-byte chunk of dims 16 ks + 8 hh (hi); the lo half is 4 chunks on
+                kh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsK + tile256_off(r32, c)));
+                kl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ldsK + tile256_off(r32, c + 4)));
+            }
+            __builtin_amdgcn_sched_barrier(0);                // all 8 fragment reads in flight before the first MFMA
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc_s = mfma32(kl[0], qh[0], zero);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) acc_s = mfma32(kl[ks], qh[ks], acc_s);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc_s = mfma32(kh[ks], ql[ks], acc_s);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc_s = mfma32(kh[ks], qh[ks], acc_s);
+        }
+        // V fragments (hardware-transposed reads), requested now and consumed after the softmax; inline asm for the reason given in
+        // attention_16_long_kernel (for the builtin hipcc would first drain the LDS-DMA copies in flight).  vf[step][db][hi / lo][half]:
+        // A operand of k-step `step` (16 keys) for dim block db; element j <-> key 16 step + 8 (j >> 2) + 4 hh + (j & 3), dim
+        // 32 db + 16 dh + li
+        s16x4 vf[2][2][2][2];
+        {
+            const lds_u8* vbase = (const lds_u8*)(ldsK + 32 * 256) + v_row * 256 + 8 * (li & 3);
+#define VITVS_TRX(dst, va, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(OFF))
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const unsigned va = (unsigned)(size_t)vbase + 32u * (unsigned)((4 * db + 2 * pl + dh) ^ v_sw);   // hi window, lo two on
+                    VITVS_TRX(vf[0][db][pl][0], va, 0);        VITVS_TRX(vf[0][db][pl][1], va, 2048);
+                    VITVS_TRX(vf[1][db][pl][0], va, 4096);     VITVS_TRX(vf[1][db][pl][1], va, 4096 + 2048);
+                }
+#undef VITVS_TRX
+        }
+        // online softmax of the lane's 16 scores (one query; the other half of its keys sits in lane ^ 32).  The vector pipe is this
+        // kernel's longer resource (section 9 of the notes), so: statistics on the RAW scores with hd^-0.5 log2 e folded into the
+        // exponent's fma, packed fp32 arithmetic, the key mask behind a real branch (only the sequence's last tile has masked keys; the
+        // empty asm keeps hipcc from turning the branch into 48 selects on every tile)
+        if (kb0 + 32 > N) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (kb0 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) acc_s[i] = -INFINITY;
+        }
+        float mloc = fmaxf(acc_s[0], acc_s[1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mloc = fmaxf(fmaxf(mloc, acc_s[i]), acc_s[i + 1]);
+        mloc = fmaxf(mloc, lane_xor32(mloc));
+        const float m_new = fmaxf(m_run, mloc);               // finite: a tile's first key is valid
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {
+            const float alpha = fast_exp2((m_run - m_new) * kScaleLog2e);   // 0 on the first tile (O = l = 0 anyway)
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_o[db][i] *= alpha;
+            m_run = m_new;
+        }
+        const float shift = 8.0f - m_run * kScaleLog2e;       // p' = 2^8 p: the lo halves of all but negligible weights are normal fp16
+        float psum = 0.f;                                     // ONE scalar chain on purpose: hipcc packs two chains into v_pk_add_f32, which costs more than its two halves beside MFMAs
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float p[2] = {fast_exp2(__builtin_fmaf(acc_s[8 * st + j], kScaleLog2e, shift)),
+                                    fast_exp2(__builtin_fmaf(acc_s[8 * st + j + 1], kScaleLog2e, shift))};
+                psum += p[0];
+                psum += p[1];
+                const f16x2 hi = {(f16)p[0], (f16)p[1]};
+                const f16x2 lo = split_lo_pair(hi, p[0], p[1]);
+                ph[st][j] = hi[0];
+                ph[st][j + 1] = hi[1];
+                pl[st][j] = lo[0];
+                pl[st][j + 1] = lo[1];
+            }
+        l_run += psum;
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vf[0][0][0][0]), "+v"(vf[0][0][0][1]), "+v"(vf[0][0][1][0]), "+v"(vf[0][0][1][1]), "+v"(vf[0][1][0][0]), "+v"(vf[0][1][0][1]),
+                       "+v"(vf[0][1][1][0]), "+v"(vf[0][1][1][1]), "+v"(vf[1][0][0][0]), "+v"(vf[1][0][0][1]), "+v"(vf[1][0][1][0]), "+v"(vf[1][0][1][1]),
+                       "+v"(vf[1][1][0][0]), "+v"(vf[1][1][0][1]), "+v"(vf[1][1][1][0]), "+v"(vf[1][1][1][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        // O^T[dim][query] += V^T P^T, 2 k-steps of 16 keys x 2 dim blocks x (lo.hi + hi.lo + hi.hi)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const s16x4 h0 = vf[st][db][0][0], h1 = vf[st][db][0][1], l0 = vf[st][db][1][0], l1 = vf[st][db][1][1];
+                const f16x8 vh = __builtin_bit_cast(f16x8, (s16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+                const f16x8 vl = __builtin_bit_cast(f16x8, (s16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+                acc_o[db] = mfma32(vl, ph[st], acc_o[db]);
+                acc_o[db] = mfma32(vh, pl[st], acc_o[db]);
+                acc_o[db] = mfma32(vh, ph[st], acc_o[db]);
+            }
+    }
+    l_run += lane_xor32(l_run);                               // both lane halves hold the query's whole sum
+    // acc_o[db][i] = O[query r32][dim 32 db + (i & 3) + 8 (i >> 2) + 4 hh] * l
+    const float inv = 1.0f / l_run;
+    const int q = q0 + r32;
+    if (q < N) {
+        hx2* dst = out + ((size_t)img * N + q) * D * 2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                store_x2<false>(dst, h * 64 + 32 * db + 8 * g4 + 4 * hh,
+                                f32x4{acc_o[db][4 * g4] * inv, acc_o[db][4 * g4 + 1] * inv, acc_o[db][4 * g4 + 2] * inv, acc_o[db][4 * g4 + 3] * inv});
+    }
+}
+
 // ------------------------------------------------------------------------------------ bf16, short sequences
 // N <= 256 (the 197 tokens of a 224² frame): one workgroup = 16 queries of one (image, head), wave w = key tile w.
 // Every wave requests its whole input at entry in one memory round trip — Q and its 64 keys straight into MFMA
@@ -1047,46 +1282,51 @@ __global__ __launch_bounds__(256 * KS) void attention_x2_kernel(const hx2* __res
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4], qh[s], acc_s[t4]);
         }
-        float mloc = -INFINITY;
+        // online softmax of the lane's 16 scores.  Trimmed for the vector pipe, which is this kernel's longer resource (profiles/
+        // r05_notes.md section 9): statistics on the RAW scores with hd^-0.5 log2 e folded into the exponent's fma, packed fp32
+        // arithmetic, the key mask and the rescale of O behind real branches (masked keys: the sequence's last tile only)
+        if (kb + 64 > N) {
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + 16 * t4 + 4 * g + r;
-                float x = acc_s[t4][r] * kScaleLog2e;
-                x = (key < N) ? x : -INFINITY;
-                acc_s[t4][r] = x;
-                mloc = fmaxf(mloc, x);
+                for (int r = 0; r < 4; ++r)
+                    if (kb + 16 * t4 + 4 * g + r >= N) acc_s[t4][r] = -INFINITY;
+        }
+        const float mloc = rows_max(max16(acc_s));
+        const float m_new = fmaxf(m_run, mloc);               // finite: a tile's first key is valid
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {
+            const float alpha = fast_exp2((m_run - m_new) * kScaleLog2e);   // 0 on a first tile (O = l = 0 anyway)
+            l_run *= alpha;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+            m_run = m_new;
+        }
+        const float shift = 8.0f - m_run * kScaleLog2e;       // p' = 2^8 p (header)
+        float psum = 0.f;                                     // ONE scalar chain on purpose: hipcc packs two chains into v_pk_add_f32, which costs more than its two halves beside MFMAs
+        f16x8 phs[2], pls[2];
+        // k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x4 a = acc_s[2 * u + (j >> 2)];
+                const float p[2] = {fast_exp2(__builtin_fmaf(a[j & 3], kScaleLog2e, shift)), fast_exp2(__builtin_fmaf(a[(j & 3) + 1], kScaleLog2e, shift))};
+                psum += p[0];
+                psum += p[1];
+                const f16x2 hi = {(f16)p[0], (f16)p[1]};
+                const f16x2 lo = split_lo_pair(hi, p[0], p[1]);
+                phs[u][j] = hi[0];
+                phs[u][j + 1] = hi[1];
+                pls[u][j] = lo[0];
+                pls[u][j + 1] = lo[1];
             }
-        mloc = rows_max(mloc);
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
-        const float shift = 8.0f - m_new;                     // p' = 2^8 p (header)
-        float psum = 0.f;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(acc_s[t4][r] + shift);
-                acc_s[t4][r] = p;
-                psum += p;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int td = 0; td < 4; ++td) acc_o[td] *= alpha;
+        l_run += psum;
 
-        // O^T += V^T P^T ; k-slot (g, j) of step u  <->  key 32u + 16(j>>2) + 4g + (j&3)
+        // O^T += V^T P^T
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            f16x8 ph, pl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = acc_s[2 * u + (j >> 2)][j & 3];
-                const f16 hi = (f16)p;
-                ph[j] = hi;
-                pl[j] = (f16)(p - (float)hi);
-            }
+            const f16x8 ph = phs[u], pl = pls[u];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
                 // head dims 16 td .. 16 td + 15: hi halves in window 4 (td >> 1) + (td & 1) of a key row, lo halves two windows on
@@ -1122,7 +1362,7 @@ __global__ __launch_bounds__(256 * KS) void attention_x2_kernel(const hx2* __res
             const f32x4* other = buf + o * 5 * 256;
             const f32x4 ml = other[4 * 256];
             const float m_tot = fmaxf(m_run, ml[0]);
-            const float wa = fast_exp2(m_run - m_tot), wb = fast_exp2(ml[0] - m_tot);
+            const float wa = fast_exp2((m_run - m_tot) * kScaleLog2e), wb = fast_exp2((ml[0] - m_tot) * kScaleLog2e);   // (m: raw scores)
             m_run = m_tot;
             l_run = l_run * wa + ml[1] * wb;
 #pragma unroll
@@ -1226,40 +1466,41 @@ __global__ __launch_bounds__(256) void attention_x2_short_kernel(const hx2* __re
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) acc_s[t4] = mfma16(kh[t4][s], qh[s], acc_s[t4]);
         }
-        float mloc = -INFINITY;
+        // softmax of the lane's 16 scores, trimmed as in attention_x2_kernel: statistics on the RAW scores (m_run in raw units, the
+        // merge below applies hd^-0.5 log2 e), the scale folded into the exponent's fma, packed fp32 arithmetic, the key mask behind a
+        // branch (only a sequence's last tile has masked keys)
+        if (kb + 64 > N) {
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+            for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + 16 * t4 + 4 * g + r;
-                float x = acc_s[t4][r] * kScaleLog2e;
-                x = (key < N) ? x : -INFINITY;
-                acc_s[t4][r] = x;
-                mloc = fmaxf(mloc, x);
-            }
-        m_run = rows_max(mloc);               // the tile's first key is valid (kb < N), so this is finite
-        const float shift = 8.0f - m_run;     // p' = 2^8 p: the lo halves of all but negligible weights are normal fp16 numbers
-        float psum = 0.f;
+                for (int r = 0; r < 4; ++r)
+                    if (kb + 16 * t4 + 4 * g + r >= N) acc_s[t4][r] = -INFINITY;
+        }
+        m_run = rows_max(max16(acc_s));       // the tile's first key is valid (kb < N), so this is finite
+        const float shift = 8.0f - m_run * kScaleLog2e;   // p' = 2^8 p: the lo halves of all but negligible weights are normal fp16 numbers
+        float psum = 0.f;                                     // ONE scalar chain on purpose: hipcc packs two chains into v_pk_add_f32, which costs more than its two halves beside MFMAs
+        f16x8 phs[2], pls[2];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(acc_s[t4][r] + shift);
-                acc_s[t4][r] = p;
-                psum += p;
+            for (int j = 0; j < 8; j += 2) {
+                const f32x4 a = acc_s[2 * u + (j >> 2)];
+                const float p[2] = {fast_exp2(__builtin_fmaf(a[j & 3], kScaleLog2e, shift)), fast_exp2(__builtin_fmaf(a[(j & 3) + 1], kScaleLog2e, shift))};
+                psum += p[0];
+                psum += p[1];
+                const f16x2 hi = {(f16)p[0], (f16)p[1]};
+                const f16x2 lo = split_lo_pair(hi, p[0], p[1]);
+                phs[u][j] = hi[0];
+                phs[u][j + 1] = hi[1];
+                pls[u][j] = lo[0];
+                pls[u][j + 1] = lo[1];
             }
         l_run = rows_sum(psum);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's V slab has landed (its own LDS-DMA copies)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            f16x8 ph, pl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = acc_s[2 * u + (j >> 2)][j & 3];
-                const f16 hi = (f16)p;
-                ph[j] = hi;
-                pl[j] = (f16)(p - (float)hi);
-            }
+            const f16x8 ph = phs[u], pl = pls[u];
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
                 const int wh = 4 * (td >> 1) + (td & 1);
@@ -1297,7 +1538,7 @@ __global__ __launch_bounds__(256) void attention_x2_short_kernel(const hx2* __re
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float wk = fast_exp2(m_k[k] - m_tot);          // 0 for a wave without keys (m = -inf)
+        const float wk = fast_exp2((m_k[k] - m_tot) * kScaleLog2e);   // (m: raw scores) 0 for a wave without keys (m = -inf)
         l_tot += l_k[k] * wk;
         const f32x4 ok = reinterpret_cast<const f32x4*>(smem + k * 16384)[wave * 64 + lane];
 #pragma unroll
@@ -1441,7 +1682,13 @@ int launch_attention(Precision p, const void* qkv, void* out, int n_img, int N, 
         const int items16 = ((N + 15) / 16) * H * n_img;
         if (N <= 256 && items16 <= 640 && (long)n_img * N * 12 * D < (1l << 32))
             launch(attention_x2_short_kernel, dim3(8 * ((items16 + 7) / 8)), dim3(256), 4 * 16384, stream, (const hx2*)qkv, (hx2*)out, N, D, n_img);
-        else if ((long)nt * H * n_img <= 256 && nt >= 2)
+        else if (N >= 2048 && (long)n_img * N * 12 * D < (1l << 32)) {
+            // (measured on one box, generic | this kernel, back to back on random operands: 2 x 3137 x 12 275 | 252 us, 2 x 1370 x 16 70 | 74 us,
+            //  2 x 485 x 6 11.5 | 18 us: it pays from a few thousand tokens on, where the generic kernel's 64-query workgroups stage
+            //  K / V through registers twice as often)
+            const int items = ((N + 127) / 128) * H * n_img, g_per_xcd = (items + 7) / 8;
+            launch(attention_x2_long_kernel, dim3(8 * g_per_xcd), dim3(256), 3 * 2 * 32 * 256, stream, (const hx2*)qkv, (hx2*)out, N, D, n_img, g_per_xcd);
+        } else if ((long)nt * H * n_img <= 256 && nt >= 2)
             launch((attention_x2_kernel<2>), grid, dim3(512), 2 * 2 * 64 * 256, stream, (const hx2*)qkv, (hx2*)out, N, D);
         else
             launch((attention_x2_kernel<1>), grid, dim3(256), 2 * 64 * 256, stream, (const hx2*)qkv, (hx2*)out, N, D);

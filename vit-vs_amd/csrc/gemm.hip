@@ -291,10 +291,9 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
             if (wgs <= 256 && wgs > best) { best = wgs; bn = c; }
         }
         if (best < 0) bn = (N % 128 == 0) ? 128 : 64;
-        // EXPERIMENT (tools/quick_rate.py, removed once measured): beside other queues' launches, a wider column tile for the one-round
-        // launches (fewer re-reads of the activation rows; fewer, fatter workgroups)
-        static const int wide_exp = [] { const char* e = getenv("VITVS_EXP_WIDE_TILES"); return e ? atoi(e) : 0; }();
-        if (wide_exp && g_updates_in_flight >= 2 && N % wide_exp == 0 && mt * (N / wide_exp) <= 256) bn = wide_exp;
+        // (Measured in round 5 and not kept: beside other queues' launches a wider column tile for these one-round launches — fewer
+        //  re-reads of the activation rows, fewer and fatter workgroups — 96 / 128 columns wherever they divide: bf16 3942 -> 3969 /
+        //  3748 updates/s with three in flight, f16x2 2402 -> 2311 / 2067.)
     }
     const long wgs = mt * (N / bn) * splits;
     // Alone on the chip a one-round launch wants its serial k-loop short: two k-groups (8 waves, 112-144 KB of LDS, one
