@@ -941,9 +941,14 @@ def run_rank(args):
             v_out, st_out = np.zeros((B, 6), np.float64), np.zeros(B, np.int32)
             eng.set_option("in_flight", 1)
 
+            # (argument pointers built once: a C caller passes addresses, and eight numpy -> ctypes conversions per call are ~10 us of
+            #  interpreter time inside a 0.5 ms call)
+            p_cur, p_des, p_z, p_k, p_v, p_st = hp(cur_np), hp(des_np), hp(z_host), hp(k_host), hp(v_out), hp(st_out)
+            p_orders = [hp(orders_host[j]) for j in range(8)]
+            call_host = eng.lib.vitvs_compute_velocity
+
             def host_step(i):
-                rc = eng.lib.vitvs_compute_velocity(eng.handle, B, hp(cur_np), hp(des_np), 0, hp(z_host), hp(k_host), _lib.SELECT_ORDER,
-                                                    hp(orders_host[i % 8]), None, 0, hp(v_out), hp(st_out))
+                rc = call_host(eng.handle, B, p_cur, p_des, 0, p_z, p_k, _lib.SELECT_ORDER, p_orders[i % 8], None, 0, p_v, p_st)
                 if rc != 0:
                     raise RuntimeError(f"vitvs_compute_velocity failed ({rc})")
             h_steps = max(10, args.steps // 2)
