@@ -218,3 +218,54 @@ def test_controller_asks_for_a_refused_frame_geometry_only_once():
     assert eng.asked == [(480, 640)] and eng.resized == 10          # asked once, resized every time
     ctl._path_frames(np.zeros((240, 320, 3), np.uint8), np.zeros((240, 320, 3), np.uint8))
     assert eng.asked == [(480, 640), (240, 320)]                     # another geometry is another question
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The Controller's default selection draws on the host between two device calls: the fast form of that draw (integer part in numpy,
+# `torch.randperm(n, generator=g)` instead of swapping the global RNG's state) must BE the reference-shaped one.
+
+def _draw_with_global_rng(nn_1, nn_2, sim_1, grid, k, gen):
+    """The draw as the reference runs it (vitvs_v2.py:84-141): global RNG, tensors, `_candidate_order`."""
+    state = torch.get_rng_state()
+    torch.set_rng_state(gen.get_state())
+    try:
+        t = nn_1.numel()
+        if sim_1.mean().item() > 0.99:
+            return torch.randperm(t)[:min(k, t)]
+        cand = servo._candidate_order(nn_1, nn_2, grid)
+        kk = min(k, cand.numel())
+        return None if kk == 0 else cand[torch.randperm(cand.numel())[:kk]]
+    finally:
+        gen.set_state(torch.get_rng_state())
+        torch.set_rng_state(state)
+
+
+def test_host_draw_is_the_reference_shaped_draw_on_random_and_degenerate_tables():
+    rng = np.random.default_rng(0)
+    for case in range(400):
+        g = int(rng.choice([14, 16, 22, 37]))
+        t = g * g
+        kind = case % 5
+        nn1, nn2 = rng.integers(0, t, t), rng.integers(0, t, t)
+        if kind == 0:                                        # some mutual pairs
+            idx = rng.permutation(t)[:rng.integers(1, t)]
+            nn2[nn1[idx]] = idx
+        elif kind == 1:                                      # all mutual
+            nn1 = rng.permutation(t)
+            nn2 = np.argsort(nn1)
+        elif kind == 2:                                      # none mutual: the candidates are the smallest displacement's ties
+            nn1 = nn2 = (np.arange(t) + 1) % t
+        elif kind == 3:
+            nn1 = np.minimum(np.arange(t) + g, t - 1)
+            nn2 = np.maximum(np.arange(t) - g + rng.integers(-1, 2, t), 0)
+        sim = (rng.random(t) * (1.0 if kind != 4 else 0.001) + (0.0 if kind != 4 else 0.995)).astype(np.float32)   # kind 4: same-image shortcut
+        k = int(rng.integers(1, 60))
+        ga, gb = torch.Generator().manual_seed(case), torch.Generator().manual_seed(case)
+        a = _draw_with_global_rng(torch.from_numpy(nn1).long(), torch.from_numpy(nn2).long(), torch.from_numpy(sim), g, k, ga)
+        b = servo._draw_like_the_reference(nn1.astype(np.int32), nn2.astype(np.int32), sim, g, k, gb)
+        assert (a is None and b is None) or torch.equal(a, b), (case, kind)
+        assert torch.equal(ga.get_state(), gb.get_state()), "the draw consumed a different amount of the RNG stream"
+        # tensors in: the same function's other branch
+        gc = torch.Generator().manual_seed(case)
+        c = servo._draw_like_the_reference(torch.from_numpy(nn1).long(), torch.from_numpy(nn2).long(), torch.from_numpy(sim), g, k, gc)
+        assert (a is None and c is None) or torch.equal(a, c)

@@ -124,15 +124,7 @@ def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator, num_pairs=N
     k = engine.params.num_pairs if num_pairs is None else int(num_pairs)
 
     def draw(nn_1, nn_2, sim_1):
-        if generator is not None:
-            state = torch.get_rng_state()
-            torch.set_rng_state(generator.get_state())
-        try:
-            return _draw_like_the_reference(nn_1, nn_2, sim_1, engine.cfg.grid, k)
-        finally:
-            if generator is not None:
-                generator.set_state(torch.get_rng_state())
-                torch.set_rng_state(state)
+        return _draw_like_the_reference(nn_1, nn_2, sim_1, engine.cfg.grid, k, generator)
 
     host = (not torch.is_tensor(I_cur) and not torch.is_tensor(I_des) and I_des is not None
             and tuple(np.asarray(I_cur).shape[-3:-1]) == tuple(engine.frame_size)
@@ -141,7 +133,7 @@ def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator, num_pairs=N
         order = np.arange(engine.tokens, dtype=np.int32)
         _, st0 = engine.compute_velocity_host(I_cur, I_des, Z, K, _lib.SELECT_ORDER, order, num_pairs=k)
         tab = engine.last_tables(1)
-        ids = draw(torch.from_numpy(tab["nn_1"][0]).long(), torch.from_numpy(tab["nn_2"][0]).long(), torch.from_numpy(tab["sim_1"][0]))
+        ids = draw(tab["nn_1"][0], tab["nn_2"][0], tab["sim_1"][0])
         if ids is None:                                   # (None, None, None) in the reference
             return np.zeros((1, 6)), np.array([_lib.STATUS_NO_CORRESPONDENCE], np.int32)
         v, st = engine.reselect_host(_lib.SELECT_EXPLICIT, [ids.to(torch.int32).numpy()], num_pairs=k)
@@ -159,16 +151,49 @@ def _reference_update(engine: Engine, I_cur, I_des, Z, K, generator, num_pairs=N
     return v.cpu().numpy()[None], np.array([int(st)], np.int32)
 
 
-def _draw_like_the_reference(nn_1, nn_2, sim_1, grid: int, num_pairs: int):
-    """Token ids of the desired frame as ``find_correspondences_batch`` draws them (vitvs_v2.py:84-141), or None."""
-    t = nn_1.numel()
-    if sim_1.mean().item() > 0.99:                       # same-image shortcut
-        return torch.randperm(t)[:min(num_pairs, t)]
-    cand = _candidate_order(nn_1, nn_2, grid)
+_GRID_CACHE: dict = {}
+
+
+def _candidate_order_host(nn_1: np.ndarray, nn_2: np.ndarray, grid: int) -> torch.Tensor:
+    """``_candidate_order`` on host arrays: the integer part (index arithmetic) in numpy, every floating-point step — the shifted
+    norm, the normalised spread, the descending sort whose tie order the draw inherits — through the same torch calls on the same
+    values, so the result is the same tensor (tests/test_servo_host.py compares the two over random and degenerate tables).  The
+    ``Controller``'s default selection runs this between two device calls on every update: ~15 small torch ops were 0.1 ms of it."""
+    t = int(nn_1.shape[0])
+    here = _GRID_CACHE.get((t, grid))
+    if here is None:
+        idx = np.arange(t, dtype=np.int64)
+        here = _GRID_CACHE[(t, grid)] = (idx // grid, idx % grid)
+    back = nn_2[nn_1].astype(np.int64, copy=False)
+    delta = np.empty((t, 2), np.int64)
+    np.subtract(back // grid, here[0], out=delta[:, 0])
+    np.subtract(back % grid, here[1], out=delta[:, 1])
+    dist = -torch.linalg.vector_norm((torch.from_numpy(delta) + 1e-6).to(torch.float32), 2, dim=-1)
+    spread = dist - dist.min()
+    spread = spread / (spread.max() + 1e-8)
+    vals, order = spread.sort(dim=-1, descending=True)
+    return order[vals >= 1.0]
+
+
+def _draw_like_the_reference(nn_1, nn_2, sim_1, grid: int, num_pairs: int, generator=None):
+    """Token ids of the desired frame as ``find_correspondences_batch`` draws them (vitvs_v2.py:84-141), or None.  ``generator``:
+    the torch CPU generator standing in for the reference's global RNG (``torch.randperm(n, generator=g)`` draws what
+    ``torch.randperm(n)`` draws from a global RNG in the same state; None: the global RNG itself).  Tensors or host arrays."""
+    if not torch.is_tensor(nn_1):
+        nn_1, nn_2, sim_1 = np.asarray(nn_1), np.asarray(nn_2), np.asarray(sim_1)
+        t = int(nn_1.shape[0])
+        if float(torch.from_numpy(sim_1).mean()) > 0.99:     # same-image shortcut (torch's fp32 mean, like the reference's)
+            return torch.randperm(t, generator=generator)[:min(num_pairs, t)]
+        cand = _candidate_order_host(nn_1, nn_2, grid)
+    else:
+        t = nn_1.numel()
+        if sim_1.mean().item() > 0.99:                       # same-image shortcut
+            return torch.randperm(t, generator=generator)[:min(num_pairs, t)]
+        cand = _candidate_order(nn_1, nn_2, grid)
     k = min(num_pairs, cand.numel())
     if k == 0:
         return None
-    return cand[torch.randperm(cand.numel())[:k]]
+    return cand[torch.randperm(cand.numel(), generator=generator)[:k]]
 
 
 def ema_update(state: list, v: Sequence[float], alpha: float) -> np.ndarray:
