@@ -8,7 +8,7 @@ intrinsics, weights, one visiting order per update) are resident in HBM before t
 enqueued without host synchronisation (86 launches), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
-The steps of a throughput run do not depend on each other: `value` is measured with `--in-flight` (default 3) of them
+The steps of a throughput run do not depend on each other: `value` is measured with `--in-flight` (default 4) of them
 enqueued at a time, each through its own handle on its own high-priority stream (vit-vs_amd/pipeline.py: one copy of the
 weights, graph replay per slot, the in-flight tile plan); W warm-up steps, then exactly K timed steps between barriers and
 device synchronisations, as for one stream.  The line's `sequential` object is the same W + K steps with ONE update in flight
@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent updates in flight per GPU (handles x streams, vit-vs_amd/pipeline.py); 0 = the measured "
-                         "default 3; 1 = one stream, as in rounds 1-2")
+                         "default 4; 1 = one stream, as in rounds 1-2")
     ap.add_argument("--binned", action="store_true",
                     help="3x3 log-binned descriptors (use_feature_binning: true, the reference's shipped default with "
                          "--config vits14_308: config.yaml:17, vitvs_v2.py:482-493); the Gram's K becomes 9 D")
@@ -673,10 +673,13 @@ def run_rank(args):
     # Updates of a throughput run do not depend on each other: `value` is measured with `in_flight` of them enqueued on as
     # many streams through as many handles (vit-vs_amd/pipeline.py); the one-stream figure of the earlier rounds is reported
     # beside it as `sequential`.
-    # default depth 3 (profiles/r03_notes.md section 5): the command processor overlaps the launch-to-launch floor of up to
-    # three queues (0.64 us per empty launch overall against 1.62 on one queue) and falls apart with a fourth busy one in the
-    # micro-benchmark (tools/launch_floor queues); in this benchmark a fourth update in flight measured +2 %, a fifth -17 %
-    in_flight = args.in_flight if args.in_flight > 0 else 3
+    # default depth 4 = the hardware queues HIP gives a priority class (one slot per queue; a fifth stream shares one and the rate
+    # falls 17 %).  Rounds 3-4 ran three: the empty-launch micro-benchmark overlaps the launch floor of up to three queues
+    # (tools/launch_floor) and a fourth update had measured +2 %.  Round 5 swept it in the driver's own form (--steps 20 --warmup 5,
+    # three runs each, one box: 3840-3909 with three, 3994-4050 with four) and over the other configurations (2 / 4 pairs +4 %,
+    # ViT-S +3-4 %, f16x2 +4 %, ViT-B/8 +1 %, ViT-L/14 and 8 pairs +-1 %): profiles/r05_driver_form_depth_sweep.txt,
+    # r05_depth3_vs_4.txt
+    in_flight = args.in_flight if args.in_flight > 0 else 4
     pipe = None
     if in_flight > 1:
         from vitvs_amd.pipeline import UpdatePipeline

@@ -4,7 +4,9 @@ One update at one frame pair is a chain of 86 dependent launches that leaves mos
 launch pays the launch-to-launch floor and its own ramp).  Updates that do not depend on each other — several cameras or
 control loops sharing the GPU, or a frame stream handled as a pipeline — overlap when they are enqueued through different
 handles on different HIP streams (measured on MI355X, ViT-B/16 224², bf16: 2220 updates/s on one stream, 2830 / 3110 with
-2 / 3 in flight, 3390 with the 4-wave GEMM plan the ``in_flight`` hint selects; profiles/r03_notes.md section 5).
+2 / 3 in flight, 3390 with the 4-wave GEMM plan the ``in_flight`` hint selects; profiles/r03_notes.md section 5; round 5, the
+driver's 20-step form of bench.py: 3340 / 3870 / 4020 / 3260 updates/s at depth 2 / 3 / 4 / 5 — four is the number of hardware
+queues HIP gives a priority class, a fifth stream shares one; profiles/r05_driver_form_depth_sweep.txt).
 
 ``UpdatePipeline`` is that arrangement: ``depth`` handles (own workspaces, one call in flight per handle, include/vitvs.h;
 the weights are uploaded once and borrowed by the others, vitvs_share_weights) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
@@ -31,7 +33,7 @@ class UpdatePipeline:
     statistics its arg-max correspondences follow the fp32 reference's far less closely.  A slot's output buffers are reused every ``depth`` submissions: read (or ``result``) a ticket before
     submitting ``depth`` more."""
 
-    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 3,
+    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 4,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
                  plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True,
                  stage_inputs: bool = False, streams: Optional[List[torch.cuda.Stream]] = None):
