@@ -30,10 +30,10 @@ def _orders(cfg, n, dev, seed=121):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32", "f16x2"])
-@pytest.mark.parametrize("hint", [False, True])
-def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint):
-    """11 updates over 4 different frame pairs and 11 visiting orders through a pipeline of depth 3 against the same updates,
-    one at a time, through a single handle with the same plan."""
+@pytest.mark.parametrize("hint,depth", [(False, 3), (True, 3), (True, 4)])
+def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint, depth):
+    """11 updates over 4 different frame pairs and 11 visiting orders through a pipeline of depth 3 (rounds 3-4's bench protocol) or 4
+    (bench.py's default since round 5) against the same updates, one at a time, through a single handle with the same plan."""
     dev = torch.device("cuda", 0)
     cfg = config.baseline_config("vits16_224")
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=False)
@@ -45,7 +45,7 @@ def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint
 
     eng = Engine(cfg, params, precision=precision, max_pairs=1).load_state_dict(sd)
     if hint:
-        eng.set_option("in_flight", 3)
+        eng.set_option("in_flight", depth)
     want = []
     for i in range(n):
         v, s = eng.compute_velocity_dev(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i])
@@ -53,12 +53,12 @@ def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint
     assert all(int(s[0]) == _lib.STATUS_OK for _, s in want)
     assert len({w[0].tobytes() for w in want}) > 4        # the updates really differ (pairs and orders)
 
-    pipe = UpdatePipeline(cfg, params, sd, precision=precision, depth=3, plan_hint=hint)
+    pipe = UpdatePipeline(cfg, params, sd, precision=precision, depth=depth, plan_hint=hint)
     got = {}
     tickets = []
     for i in range(n):
         tickets.append(pipe.submit(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i]))
-        if len(tickets) == 3:                                   # never more than `depth` unread results
+        if len(tickets) == depth:                               # never more than `depth` unread results
             t = tickets.pop(0)
             got[t] = pipe.result(t)
     for t in tickets:
@@ -68,7 +68,7 @@ def test_pipelined_updates_equal_the_one_stream_call_bit_for_bit(precision, hint
         assert np.array_equal(v.cpu().numpy(), want[i][0]), f"update {i}"
         assert np.array_equal(s.cpu().numpy(), want[i][1])
     # a second pass replays the captured graphs: still the same bits
-    t2 = [pipe.submit(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i]) for i in range(3)]
+    t2 = [pipe.submit(cur[i % 4], des[i % 4], Z, K, _lib.SELECT_ORDER, orders[i]) for i in range(depth)]
     for i, t in enumerate(t2):
         assert np.array_equal(pipe.result(t)[0].cpu().numpy(), want[i][0])
     pipe.close()

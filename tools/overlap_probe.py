@@ -1,3 +1,10 @@
+"""bench.py's `roofline.overlapped` measurement (captured proj / fc2 chains of the dominant GEMM symbol, one chain per queue) for 1, 2, 3
+and 4 queues, with N high-priority streams already created in the process (the pipeline's own) — the record behind
+profiles/r05_overlap_queues.txt: the chain's per-launch time is not monotonic in the queue count (3 queues are slower than 2, 4 much
+faster), whatever streams exist beside it.
+
+  python tools/overlap_probe.py [pre-existing high-priority streams]
+"""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import torch
