@@ -61,6 +61,10 @@ class UpdatePipeline:
         # precision measured beside the first, would otherwise put 2 x depth high-priority streams on the class's four queues.)
         if streams is not None and len(streams) != self.depth:
             raise VitvsError("streams: one per slot")
+        # (More than four queues do not help: measured in round 5, 300-step bench — slots 5+ on default-class streams, i.e. on other
+        # hardware queues: 1463 / 1763 / 1943 updates/s at depth 5 / 6 / 8 against 4462 at depth 4; GPU_MAX_HW_QUEUES=8 with every slot
+        # high-priority: 1573 / 1833 / 2373.  With more than four hardware queues active the scheduler time-slices them; five streams
+        # SHARING four queues lose less, 3429-3502.  profiles/r05_notes.md section 10.)
         self.streams = list(streams) if streams is not None else \
             [torch.cuda.Stream(device=self.device, priority=stream_priority) for _ in range(self.depth)]
         self.done = [torch.cuda.Event() for _ in range(self.depth)]
