@@ -482,7 +482,8 @@ int splitk_slices(Precision p, int M, int N, int K) {
         if (tiles * c <= 256) best = c;
     }
     // Beside other queues' launches (vitvs_set_option "in_flight") the chip is filled by THEIR workgroups: a third K slice
-    // only adds partial sums for residual_ln to read (ViT-B/16 224², 4 in flight, same box: 3946 -> 4075 updates/s with 2).
+    // only adds partial sums for residual_ln to read (ViT-B/16 224², 4 in flight, same box: 3946 -> 4075 updates/s with 2; ONE slice:
+    // 4301-4348 -> 4045-4091, round 5 — 84 workgroups with 48 k-tiles each are too long a chain).
     if (g_updates_in_flight >= 2 && best > 2) best = 2;
     return best;
 }
