@@ -21,7 +21,7 @@ def main():
     key = sys.argv[2] if len(sys.argv) > 2 else "vitb16_224"      # e.g. vitb8_448: the key-split long-sequence attention
     binned = len(sys.argv) > 3 and sys.argv[3] == "binned"        # the stencil form of the binned Gram (raw Gram workspace per slot)
     depth = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-    npairs = 8 if depth % 2 else 7                                # coprime with the depth: every pair meets every slot
+    npairs = int(os.environ.get("SOAK_PAIRS", 8 if depth % 2 else 7))   # coprime with the depth: every pair meets every slot
     dev = torch.device("cuda", 0)
     cfg = config.baseline_config(key)
     params = config.ServoParams(dino_input_size=cfg.img_size, use_feature_binning=binned)

@@ -8,6 +8,13 @@ handles on different HIP streams (measured on MI355X, ViT-B/16 224², bf16: 2220
 driver's 20-step form of bench.py: 3340 / 3870 / 4020 / 3260 updates/s at depth 2 / 3 / 4 / 5 — four is the number of hardware
 queues HIP gives a priority class, a fifth stream shares one; profiles/r05_driver_form_depth_sweep.txt).
 
+Depth 4 is the best only while NOTHING else of the process keeps a queue busy: the chip runs four hardware queues side by side and
+time-slices a fifth.  A caller that reads every result through torch's default stream (``result()``'s clones, a ``.cpu()``), copies
+its inputs there, or runs an RCCL collective per update on the communicator's stream has that fifth queue — measured with a host read
+per update, 8000 updates: 3960-4107 updates/s at depth 3 against 3652-3663 at depth 4 (profiles/r05_notes.md section 10).  Hence the
+default of 3 here; bench.py passes 4 for its single-GPU `value`, whose timed region touches no other stream, and 3 when every update is
+followed by an all-gather.
+
 ``UpdatePipeline`` is that arrangement: ``depth`` handles (own workspaces, one call in flight per handle, include/vitvs.h;
 the weights are uploaded once and borrowed by the others, vitvs_share_weights) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
 makes cheap enough (~50 us of host time per update).  Every update is the same computation as ``Engine.compute_velocity_dev``
@@ -33,7 +40,7 @@ class UpdatePipeline:
     statistics its arg-max correspondences follow the fp32 reference's far less closely.  A slot's output buffers are reused every ``depth`` submissions: read (or ``result``) a ticket before
     submitting ``depth`` more."""
 
-    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 4,
+    def __init__(self, cfg: ViTConfig, params: ServoParams, state_dict, *, precision: str = "fp16", depth: int = 3,
                  max_pairs: int = 1, max_rows: Optional[int] = None, device=None, graph_replay: bool = True,
                  plan_hint: bool = True, stream_priority: int = -1, share_weights: bool = True,
                  stage_inputs: bool = False, streams: Optional[List[torch.cuda.Stream]] = None):
