@@ -753,10 +753,15 @@ def run_rank(args):
     v_all_slots = [torch.zeros((world * B, 6), dtype=torch.float64, device=dev) for _ in range(in_flight)] if (multi and pipe) else None
 
     def pipe_step(i):
+        # inputs_ready: the frames, depth image, intrinsics and visiting orders are device-resident and complete since before the fence
+        # that opens the timed region (the contract's "inputs already resident in HBM").  Without it every submission records an event
+        # on THIS stream for the slot to wait on — traffic on a fifth hardware queue beside the slots' four, which the chip time-slices:
+        # same box, 300 steps 4315-4367 -> 4684-4769 updates/s, the driver's 20-step form 3951-4052 -> 4205-4323
+        # (profiles/r05_ab_inputs_ready.txt)
         if dense:
-            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False)
+            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_DENSE, None, None, False, inputs_ready=True)
         else:
-            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+            t = pipe.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, inputs_ready=True)
         if do_gather:                               # the update's v_c all-gather, behind it on its own stream
             v_k, _, st_k = pipe.slot(t)
             with torch.cuda.stream(st_k):
@@ -901,7 +906,7 @@ def run_rank(args):
                 pipe_x2 = UpdatePipeline(cfg, params, sd, precision="f16x2", depth=in_flight, max_pairs=B, device=dev, streams=pipe.streams)
 
                 def x2_step(i):
-                    pipe_x2.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+                    pipe_x2.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, inputs_ready=True)
 
                 def x2_fence():
                     pipe_x2.synchronize()
@@ -1017,7 +1022,7 @@ def run_rank(args):
             pipe16 = UpdatePipeline(cfg, params, sd, precision="fp16", depth=in_flight, max_pairs=B, device=dev, streams=pipe.streams)
 
             def step16(i):
-                pipe16.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False)
+                pipe16.submit(I_cur, I_des, Z, K, _lib.SELECT_ORDER, orders[i % total], None, False, inputs_ready=True)
 
             def fence16():
                 pipe16.synchronize()

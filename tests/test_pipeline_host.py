@@ -48,7 +48,7 @@ class _FakeStream:
         _FakeStream.made.append(self)
 
     def wait_stream(self, other):
-        pass
+        self.waits = getattr(self, "waits", 0) + 1
 
     def wait_event(self, ev):
         pass
@@ -125,3 +125,14 @@ def test_round_robin_and_the_ticket_window(fake):
 def test_depth_must_be_positive(fake):
     with pytest.raises(VitvsError):
         pipeline.UpdatePipeline("cfg", "params", {}, depth=0)
+
+
+def test_inputs_ready_skips_the_event_on_the_callers_stream(fake):
+    """`submit(..., inputs_ready=True)`: the slot does not wait for (= records no event on) the caller's stream — on the GPU that event
+    is traffic on one more hardware queue beside the slots' own (bench.py's timed region passes it; the default keeps the wait)."""
+    p = pipeline.UpdatePipeline("cfg", "params", {}, depth=2)
+    p.submit("cur", "des", "Z", "K")
+    p.submit("cur", "des", "Z", "K", inputs_ready=True)
+    p.submit("cur", "des", "Z", "K")
+    slot_streams = p.streams
+    assert getattr(slot_streams[0], "waits", 0) == 2 and getattr(slot_streams[1], "waits", 0) == 0

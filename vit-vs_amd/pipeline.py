@@ -104,14 +104,19 @@ class UpdatePipeline:
     # ------------------------------------------------------------------ enqueue
     def submit(self, I_cur: torch.Tensor, I_des: Optional[torch.Tensor], Z: Optional[torch.Tensor], K: torch.Tensor,
                mode: int = _lib.SELECT_DENSE, selection: Optional[torch.Tensor] = None,
-               n_selected: Optional[torch.Tensor] = None, des_shared: bool = False, num_pairs: int = 0) -> int:
+               n_selected: Optional[torch.Tensor] = None, des_shared: bool = False, num_pairs: int = 0,
+               inputs_ready: bool = False) -> int:
         """Arguments as ``Engine.compute_velocity_dev`` (device tensors).  The slot's stream first waits for the caller's
-        current stream, so inputs produced there are complete; nothing synchronises the host.  Without ``stage_inputs`` the
-        update reads the caller's tensors in place: keep them alive and unchanged until the ticket has completed (``result``)."""
+        current stream, so inputs produced there are complete; nothing synchronises the host.  ``inputs_ready``: the caller
+        vouches that the inputs are complete already (e.g. device-resident buffers written before a synchronisation) — no event is
+        recorded on the caller's stream, which otherwise is one more hardware queue with traffic on every update (module docstring).
+        Without ``stage_inputs`` the update reads the caller's tensors in place: keep them alive and unchanged until the ticket has
+        completed (``result``)."""
         t = self.submitted
         k = t % self.depth
         st = self.streams[k]
-        st.wait_stream(torch.cuda.current_stream(self.device))
+        if not inputs_ready:
+            st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
             I_cur, I_des, Z, K = (self._stable(k, n, t) for n, t in (("cur", I_cur), ("des", I_des), ("Z", Z), ("K", K)))
             selection, n_selected = self._stable(k, "sel", selection), self._stable(k, "nsel", n_selected)
