@@ -8,7 +8,7 @@ intrinsics, weights, one visiting order per update) are resident in HBM before t
 enqueued without host synchronisation (86 launches), and with N > 1
 every step ends with an RCCL all-gather of the 6 doubles of v_c.
 
-The steps of a throughput run do not depend on each other: `value` is measured with `--in-flight` (default 4; 3 with N > 1, where the all-gather's stream is a queue of its own) of them
+The steps of a throughput run do not depend on each other: `value` is measured with `--in-flight` (default 4) of them
 enqueued at a time, each through its own handle on its own high-priority stream (vit-vs_amd/pipeline.py: one copy of the
 weights, graph replay per slot, the in-flight tile plan); W warm-up steps, then exactly K timed steps between barriers and
 device synchronisations, as for one stream.  The line's `sequential` object is the same W + K steps with ONE update in flight
@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     help="order: num_pairs features in a fresh random order (headline); dense: every mutual NN enters L_e")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent updates in flight per GPU (handles x streams, vit-vs_amd/pipeline.py); 0 = the measured "
-                         "default (4 on one GPU, 3 when an all-gather follows every update); 1 = one stream, as in rounds 1-2")
+                         "default 4; 1 = one stream, as in rounds 1-2")
     ap.add_argument("--binned", action="store_true",
                     help="3x3 log-binned descriptors (use_feature_binning: true, the reference's shipped default with "
                          "--config vits14_308: config.yaml:17, vitvs_v2.py:482-493); the Gram's K becomes 9 D")
@@ -679,12 +679,12 @@ def run_rank(args):
     # three runs each, one box: 3840-3909 with three, 3994-4050 with four) and over the other configurations (2 / 4 pairs +4 %,
     # ViT-S +3-4 %, f16x2 +4 %, ViT-B/8 +1 %, ViT-L/14 and 8 pairs +-1 %): profiles/r05_driver_form_depth_sweep.txt,
     # r05_depth3_vs_4.txt
-    # ... while nothing else keeps a queue busy: with N > 1 every update is followed by an all-gather on the communicator's own stream,
-    # a fifth active queue, which the chip time-slices (measured on one GPU with torch's default stream as the fifth queue — a host read
-    # per update: 3960-4107 updates/s at depth 3 against 3652-3663 at depth 4, profiles/r05_notes.md section 10) — so the multi-GPU
-    # line keeps the three slots of rounds 3-4 unless --no-gather
-    default_depth = 3 if (world > 1 and not args.no_gather) else 4
-    in_flight = args.in_flight if args.in_flight > 0 else default_depth
+    # ... while nothing else keeps a queue busy.  With N > 1 every update is followed by an all-gather: torch >= 2.8 launches a
+    # synchronous collective on the CURRENT stream (this image's torch 2.10 says so itself: "TORCH_NCCL_AVOID_RECORD_STREAMS is the
+    # default now"), i.e. on the slot's own queue, not on a communicator stream — in a world of one rank the kernel trace of this
+    # command shows the four slot queues and no fifth (profiles/r05_notes.md section 10), and that line gains like the others
+    # (4149 -> 4612).  On an older torch the communicator's stream would be a fifth queue: `--in-flight 3` is the arrangement for it.
+    in_flight = args.in_flight if args.in_flight > 0 else 4
     pipe = None
     if in_flight > 1:
         from vitvs_amd.pipeline import UpdatePipeline

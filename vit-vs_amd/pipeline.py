@@ -12,8 +12,8 @@ Depth 4 is the best only while NOTHING else of the process keeps a queue busy: t
 time-slices a fifth.  A caller that reads every result through torch's default stream (``result()``'s clones, a ``.cpu()``), copies
 its inputs there, or runs an RCCL collective per update on the communicator's stream has that fifth queue — measured with a host read
 per update, 8000 updates: 3960-4107 updates/s at depth 3 against 3652-3663 at depth 4 (profiles/r05_notes.md section 10).  Hence the
-default of 3 here; bench.py passes 4 for its single-GPU `value`, whose timed region touches no other stream, and 3 when every update is
-followed by an all-gather.
+default of 3 here; bench.py passes 4 for `value`, whose timed region touches no other stream (``submit(inputs_ready=True)``; the per-update
+all-gather of N > 1 is a synchronous collective, which torch >= 2.8 launches on the current = the slot's stream).
 
 ``UpdatePipeline`` is that arrangement: ``depth`` handles (own workspaces, one call in flight per handle, include/vitvs.h;
 the weights are uploaded once and borrowed by the others, vitvs_share_weights) on ``depth`` streams, filled round-robin from ONE host thread, which hipGraph replay
