@@ -293,7 +293,8 @@ static TilePlan plan_tiles(int M, int N, int nk_per_slice, int splits, bool fixe
         if (best < 0) bn = (N % 128 == 0) ? 128 : 64;
         // (Measured in round 5 and not kept: beside other queues' launches a wider column tile for these one-round launches — fewer
         //  re-reads of the activation rows, fewer and fatter workgroups — 96 / 128 columns wherever they divide: bf16 3942 -> 3969 /
-        //  3748 updates/s with three in flight, f16x2 2402 -> 2311 / 2067.)
+        //  3748 updates/s with three in flight, f16x2 2402 -> 2311 / 2067; again with four in flight and nothing on a fifth queue: bf16
+        //  4818-4841 -> 4828-4846 / 4452-4457, f16x2 2593-2636 -> 2630-2658 / 2357: 96 inside the noise, 128 -8 %.)
     }
     const long wgs = mt * (N / bn) * splits;
     // Alone on the chip a one-round launch wants its serial k-loop short: two k-groups (8 waves, 112-144 KB of LDS, one
@@ -483,7 +484,8 @@ int splitk_slices(Precision p, int M, int N, int K) {
     }
     // Beside other queues' launches (vitvs_set_option "in_flight") the chip is filled by THEIR workgroups: a third K slice
     // only adds partial sums for residual_ln to read (ViT-B/16 224², 4 in flight, same box: 3946 -> 4075 updates/s with 2; ONE slice:
-    // 4301-4348 -> 4045-4091, round 5 — 84 workgroups with 48 k-tiles each are too long a chain).
+    // 4301-4348 -> 4045-4091, round 5 — 84 workgroups with 48 k-tiles each are too long a chain; THREE slices again with four clean
+    // queues: 4818-4841 -> 4420-4464).
     if (g_updates_in_flight >= 2 && best > 2) best = 2;
     return best;
 }
