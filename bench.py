@@ -683,7 +683,8 @@ def run_rank(args):
     # synchronous collective on the CURRENT stream (this image's torch 2.10 says so itself: "TORCH_NCCL_AVOID_RECORD_STREAMS is the
     # default now"), i.e. on the slot's own queue, not on a communicator stream — in a world of one rank the kernel trace of this
     # command shows the four slot queues and no fifth (profiles/r05_notes.md section 10), and that line gains like the others
-    # (4149 -> 4612).  On an older torch the communicator's stream would be a fifth queue: `--in-flight 3` is the arrangement for it.
+    # (4149 -> 4612).  On an older torch the communicator's stream would be a fifth queue; no multi-GPU box was available to check, so
+    # the multi-GPU line calibrates before its warm-up (four slots against three, untimed; `slots_calibration` in the line).
     in_flight = args.in_flight if args.in_flight > 0 else 4
     pipe = None
     if in_flight > 1:
@@ -765,7 +766,7 @@ def run_rank(args):
         if do_gather:                               # the update's v_c all-gather, behind it on its own stream
             v_k, _, st_k = pipe.slot(t)
             with torch.cuda.stream(st_k):
-                vdist.gather_velocities(v_k, world * B, out=v_all_slots[t % in_flight])
+                vdist.gather_velocities(v_k, world * B, out=v_all_slots[t % pipe.active])
 
     def pipe_fence():
         pipe.synchronize()
@@ -782,6 +783,7 @@ def run_rank(args):
         return dict(min=round(float(lo.item()), 4), max=float(hi.item()), mean=round(float(tot.item()) / world, 4))
 
     sequential = None
+    slots_calibration = None
     with torch.cuda.stream(stream):
         if pipe is not None:
             # first the same updates one at a time on one stream — rounds 1-2's `value`, same W and K, with its per-update
@@ -800,8 +802,26 @@ def run_rank(args):
             for i in range(2 * in_flight):          # set-up, not warm-up: every slot captures its graph (first call) and
                 pipe_step(i)                        # uploads the instantiated graph (first replay) before anything is timed
             pipe_fence()
+            if world > 1 and do_gather and args.in_flight == 0 and in_flight == 4:
+                # The chip runs FOUR hardware queues side by side.  Whether the per-update all-gather keeps a fifth busy depends on the
+                # torch build (>= 2.8 launches a synchronous collective on the current = the slot's stream; older ones on the
+                # communicator's own), and no multi-GPU box was available to the builder: so the multi-GPU line finds out, untimed,
+                # before the warm-up — 16 updates with four slots, 16 with three, every rank timing its own, the job's figure being the
+                # max over ranks like `value` — and keeps three slots only if they are clearly (> 3 %) faster.
+                def calibrate(n_slots):
+                    pipe.set_active(n_slots)
+                    for i in range(2 * n_slots):
+                        pipe_step(i)
+                    pipe_fence()
+                    t_c = torch.tensor([timed_updates(None, pipe_step, pipe_fence, 2, 16, dev)], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t_c, op=dist.ReduceOp.MAX)
+                    return float(t_c.item())
+                t_four, t_three = calibrate(4), calibrate(3)
+                slots_calibration = dict(ms_16_updates_four_slots=round(t_four * 1e3, 3), ms_16_updates_three_slots=round(t_three * 1e3, 3))
+                pipe.set_active(3 if t_three < 0.97 * t_four else 4)
+                slots_calibration["chosen"] = pipe.active
             elapsed = timed_updates(None, pipe_step, pipe_fence, args.warmup, args.steps, dev)
-            last = (pipe.submitted - 1) % in_flight
+            last = (pipe.submitted - 1) % pipe.active
             v.copy_(pipe.v[last]); status.copy_(pipe.status[last])
             if do_gather:
                 v_all.copy_(v_all_slots[last])
@@ -1187,14 +1207,14 @@ def run_rank(args):
                              f"through block {cfg.layer}, cosine correspondence, mutual-NN, {params.num_pairs} features "
                              f"in a fresh random order, L_e, pinv -> v_c; I_des recomputed every update; "
                              f"{'3x3 log-binned descriptors (9 D wide); ' if binned else ''}"
-                             f"{B} pair(s) per update, {in_flight} independent update(s) in flight",
-                    key=args.config, binned=binned, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=in_flight, tokens=cfg.tokens, dim=cfg.dim,
+                             f"{B} pair(s) per update, {pipe.active if pipe is not None else 1} independent update(s) in flight",
+                    key=args.config, binned=binned, pairs_per_step_per_gpu=B, updates_in_flight_per_gpu=(pipe.active if pipe is not None else 1), tokens=cfg.tokens, dim=cfg.dim,
                     parallelism=(f"dp{world} (frame pairs sharded, " + ("no collective" if not do_gather else "v_c all-gather per step")
                                  + f"{', asynchronous' if async_gather else ''})") if world > 1 else "single GPU",
                     weights="synthetic seed 0", frame_seeds=seeds, selection="DENSE" if dense else "ORDER"),
-        protocol=(f"{in_flight} independent batch-{B} updates in flight per GPU (one handle + one high-priority stream each, shared "
+        protocol=(f"{pipe.active} independent batch-{B} updates in flight per GPU (one handle + one high-priority stream each, shared "
                   f"weights, hipGraph replay, the in_flight tile plan); the timed region is K updates between two barrier + "
-                  f"synchronize pairs, filling and draining the {in_flight} slots included" if in_flight > 1 else
+                  f"synchronize pairs, filling and draining the {pipe.active} slots included" if in_flight > 1 else
                   "one update in flight per GPU: one handle, one stream, plain launches"),
         value_one_in_flight=(sequential["value"] if sequential else round(value, 2)),
         roofline=roof,
@@ -1221,6 +1241,10 @@ def run_rank(args):
         out["per_rank_ms_per_step"] = dict(rank_ms, max=round(rank_ms["max"], 4))
         out["v_c_gather"] = ("none (--no-gather: every rank keeps its own twists)" if not do_gather else
                              "one all-gather of 6 doubles per pair behind every update")
+    if slots_calibration is not None:
+        out["slots_calibration"] = dict(slots_calibration, note="untimed, before the warm-up: 16 updates (all-gather included) with four "
+                                        "slots and with three, max over ranks; three are kept only if > 3 % faster — the chip runs four "
+                                        "hardware queues side by side and a collective on a communicator stream of its own would be a fifth")
     if gathered_ok is not None:
         out["gathered_rows_match_local"] = gathered_ok
     if ranks_seen is not None:

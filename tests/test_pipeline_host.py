@@ -136,3 +136,21 @@ def test_inputs_ready_skips_the_event_on_the_callers_stream(fake):
     p.submit("cur", "des", "Z", "K")
     slot_streams = p.streams
     assert getattr(slot_streams[0], "waits", 0) == 2 and getattr(slot_streams[1], "waits", 0) == 0
+
+
+def test_set_active_uses_the_first_slots_and_restarts_the_tickets(fake):
+    p = pipeline.UpdatePipeline("cfg", "params", {}, depth=4)
+    assert [p.submit("c", "d", "Z", "K") for _ in range(5)] == [0, 1, 2, 3, 4]
+    p.set_active(3)
+    assert p.active == 3 and p.submitted == 0
+    fake.log.clear()
+    assert [p.submit("c", "d", "Z", "K") for _ in range(4)] == [0, 1, 2, 3]
+    assert [e[1] for e in fake.log if e[0] == "update"] == [0, 1, 2, 0]          # engines 0..2 only, round-robin
+    assert p.slot(3)[2] is p.streams[0]
+    with pytest.raises(VitvsError):
+        p.slot(0)                                                                  # rewritten by ticket 3
+    with pytest.raises(VitvsError):
+        p.set_active(5)
+    p.set_active(4)
+    assert [p.submit("c", "d", "Z", "K") for _ in range(4)] == [0, 1, 2, 3]
+    assert p.slot(3)[2] is p.streams[3]

@@ -47,6 +47,7 @@ class UpdatePipeline:
         if depth < 1:
             raise VitvsError("depth must be >= 1")
         self.depth = int(depth)
+        self.active = self.depth                 # slots in use (set_active): submissions go round-robin over the first `active`
         self.engines: List[Engine] = []
         for _ in range(self.depth):
             e = Engine(cfg, params, precision=precision, max_pairs=max_pairs, max_rows=max_rows, device=device)
@@ -113,7 +114,7 @@ class UpdatePipeline:
         Without ``stage_inputs`` the update reads the caller's tensors in place: keep them alive and unchanged until the ticket has
         completed (``result``)."""
         t = self.submitted
-        k = t % self.depth
+        k = t % self.active
         st = self.streams[k]
         if not inputs_ready:
             st.wait_stream(torch.cuda.current_stream(self.device))
@@ -126,6 +127,17 @@ class UpdatePipeline:
         self.submitted = t + 1
         return t
 
+    def set_active(self, n: int):
+        """Use only the first ``n`` slots from now on (1 <= n <= depth): the pipeline is drained and ticket numbering starts again at 0.
+        For a caller that has to find out at run time how many queues are its own — the chip runs four side by side, and whatever else
+        of the process keeps a queue busy (a collective on a communicator's stream, copies on another stream) counts (module docstring);
+        bench.py calibrates its multi-GPU line with it."""
+        if not 1 <= int(n) <= self.depth:
+            raise VitvsError("active slots: 1 .. depth")
+        self.synchronize()
+        self.active = int(n)
+        self.submitted = 0
+
     def set_goal(self, I_des: torch.Tensor):
         """Cache the goal frame(s) in every handle (``Engine.set_goal``): later ``submit(..., I_des=None, ...)``."""
         for k, e in enumerate(self.engines):
@@ -136,21 +148,21 @@ class UpdatePipeline:
     # ------------------------------------------------------------------ collect
     def slot(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Stream]:
         """Output buffers (v_c [n, 6] float64, status [n] int32) and stream of ``ticket`` without waiting."""
-        if not (self.submitted - self.depth <= ticket < self.submitted):
-            raise VitvsError(f"ticket {ticket} is not in flight (submitted {self.submitted}, depth {self.depth})")
-        k = ticket % self.depth
+        if not (self.submitted - self.active <= ticket < self.submitted):
+            raise VitvsError(f"ticket {ticket} is not in flight (submitted {self.submitted}, depth {self.active})")
+        k = ticket % self.active
         return self.v[k], self.status[k], self.streams[k]
 
     def result(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Wait (host) for ``ticket`` and return copies of its ``v_c`` and ``status``."""
         v, s, _ = self.slot(ticket)
-        self.done[ticket % self.depth].synchronize()
+        self.done[ticket % self.active].synchronize()
         return v.clone(), s.clone()
 
     def join(self, stream: Optional[torch.cuda.Stream] = None):
         """Make ``stream`` (default: the current one) wait for everything submitted so far (device-side)."""
         stream = stream or torch.cuda.current_stream(self.device)
-        for k in range(min(self.depth, self.submitted)):
+        for k in range(min(self.active, self.submitted)):
             stream.wait_event(self.done[k])
 
     def synchronize(self):
