@@ -1106,7 +1106,7 @@ def run_rank(args):
         if tag == "f32":
             return "attention_f32_kernel"
         if tag == "hx2":
-            return "attention_x2_short_kernel" if short else "attention_x2_kernel"
+            return "attention_x2_short_kernel" if short else ("attention_x2_long_kernel" if cfg_.seq >= 2048 else "attention_x2_kernel")
         if short:
             return f"attention_16_short_kernel<{tag}>"
         if cfg_.seq >= 512 or (cfg_.seq >= 128 and -(-cfg_.seq // 64) * cfg_.heads * 2 * b_ > 256):
